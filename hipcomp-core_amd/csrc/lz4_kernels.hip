@@ -1,0 +1,506 @@
+// lz4_kernels.hip -- gfx950 kernels of the batched LZ4 block codec.
+//
+// Compressed bytes are those of the reference's wave64 encoder
+// (reference src/LZ4Kernels.hiph:793-969 compressStream<T>), produced by a
+// different mechanism:
+//
+//   reference                               here
+//   --------------------------------------  ---------------------------------
+//   32 KiB hash table per chunk in HBM      table in LDS (ds_read_u16 /
+//   (temp space), global_store_short        ds_write_b16); temp space unused
+//   warpMatchAny = 64-step LDS loop, twice  in-window duplicate search by one
+//   per window (:218-245)                   ds_min_u32 on a small LDS slot
+//                                           table + one ds_bpermute, exact
+//                                           fallback only for colliding lanes
+//   second warpMatchAny for the insert      insert rule (incl. the wave64
+//   (:722-741)                              `int` truncation)
+//                                           expressed as two ordered masked
+//                                           LDS stores, highest lane wins
+//   shuffleLiterals (:754-791)              one unaligned dword load per lane
+//   1 byte/lane literal + match compare     16-byte/lane copies, 4-byte/lane
+//                                           match-length compare
+//
+// One chunk per wavefront (64-thread workgroup): the window loop is a serial
+// dependency chain, the 64 lanes are the 64 window positions.
+//
+// Decoder: reference src/LZ4Kernels.hiph:971-1097 decompressStream.
+
+#include "lz4_launch.hpp"
+#include "wave_utils.hpp"
+
+#include <cstdlib>
+
+#ifndef HCAMD_LZ4_VERIFY_LDS_ORDER_DEFAULT
+#define HCAMD_LZ4_VERIFY_LDS_ORDER_DEFAULT true
+#endif
+
+namespace hcamd {
+
+namespace {
+
+constexpr uint32_t kNullOffset = 0xFFFFu;
+constexpr uint32_t kDupSlots = 1024; // ds_min slot table for in-window dups
+constexpr uint32_t kDupEmpty = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t hash_sum(uint32_t key)
+{
+  // reference hash() :557-561 before masking
+  return __brev(key) + (key ^ 0xc375u);
+}
+
+// Write `n` in LZ4's linear small-integer code: n/255 bytes of 0xFF then
+// n%255.  (reference writeLSIC :267-278)
+__device__ __forceinline__ uint32_t write_lsic(gptr out, uint32_t number, int lane)
+{
+  const uint32_t num = number / 255u + 1u;
+  const uint8_t last = (uint8_t)(number % 255u);
+  for (uint32_t i = (uint32_t)lane; i < num; i += kWave)
+    out[i] = (i + 1 < num) ? (uint8_t)0xFF : last;
+  return num;
+}
+
+// One LZ4 sequence (reference writeSequenceData :665-715, token_type
+// :280-351).  match_bytes == 0 marks the final, literal-only sequence whose
+// token low nibble is 0xC in the reference (uint8_t(0 - 4) & 0x0f).
+__device__ __forceinline__ uint32_t write_sequence(
+    gptr comp, uint32_t c, cgptr lit_src, uint32_t lit_bytes,
+    uint32_t match_bytes, uint32_t offset_bytes, int lane)
+{
+  if (lane == 0) {
+    const uint32_t lh = lit_bytes >= 15 ? 15u : lit_bytes;
+    const uint32_t mh = match_bytes >= 19 ? 15u : ((match_bytes - 4u) & 0x0fu);
+    comp[c] = (uint8_t)((lh << 4) | mh);
+  }
+  ++c;
+  if (lit_bytes >= 15)
+    c += write_lsic(comp + c, lit_bytes - 15u, lane);
+  wave_copy(comp + c, lit_src, lit_bytes, lane);
+  c += lit_bytes;
+  if (match_bytes > 0) {
+    if (lane == 0) {
+      comp[c] = (uint8_t)(offset_bytes & 0xffu);
+      comp[c + 1] = (uint8_t)((offset_bytes >> 8) & 0xffu);
+    }
+    c += 2;
+    if (match_bytes >= 19)
+      c += write_lsic(comp + c, match_bytes - 19u, lane);
+  }
+  return c;
+}
+
+// Masked LDS store of this window's positions where, for lanes that share a
+// slot, the HIGHEST lane's value must survive.  The hardware's own
+// same-address resolution inside one ds_write_b16 is not architecturally
+// documented, so the store is verified by reading back and re-issued by any
+// higher lane that lost (one pass when the hardware already keeps the
+// highest lane -- measured so on MI355X, tests/test_hw_probes.py).
+template <bool VERIFY>
+__device__ __forceinline__ void store_highest_lane_wins(
+    uint16_t* table, uint32_t hpos, uint32_t d, int lane, bool active)
+{
+  const uint16_t val = (uint16_t)((d + (uint32_t)lane) & 0xFFFFu);
+  if (!VERIFY) {
+    if (active)
+      table[hpos] = val;
+    return;
+  }
+  while (__ballot(active)) {
+    if (active)
+      table[hpos] = val;
+    uint32_t rb = active ? (uint32_t)table[hpos] : 0u;
+    // lane that produced rb: window positions are consecutive mod 65536
+    const uint32_t rb_lane = (rb - d) & 0xFFFFu;
+    active = active && (rb_lane < (uint32_t)lane);
+  }
+}
+
+// Hash-table insert for lanes [0, n) of the window at element position d,
+// with the reference's wave64 behaviour (reference
+// insertHashTableWarp :722-741, numValidThreadsToMask :717-720):
+//   n <= 31: per slot the highest lane's position is stored;
+//   n >= 32: a slot shared with lane 31 is left alone, except that lane 63
+//            stores if it is in that slot; otherwise the highest lane among
+//            lanes 0..30 of the slot stores; if the slot holds only lanes
+//            >= 32 they all store in one instruction and the hardware keeps
+//            the highest lane (HW_STORE_WINNER_HIGHEST, probed).
+template <bool VERIFY>
+__device__ __forceinline__ void insert_window(
+    uint16_t* table, uint32_t hpos, uint32_t d, int n, int lane)
+{
+  if (n <= 31) {
+    store_highest_lane_wins<VERIFY>(table, hpos, d, lane, lane < n);
+    return;
+  }
+  const uint32_t h31 = read_lane(hpos, 31);
+  const bool in31 = (hpos == h31);
+  const bool hi = lane >= 32 && lane < n && (!in31 || lane == 63);
+  const bool lo = lane < 31 && !in31;
+  store_highest_lane_wins<VERIFY>(table, hpos, d, lane, hi);
+  store_highest_lane_wins<VERIFY>(table, hpos, d, lane, lo);
+}
+
+// First mismatching element between the strings at elements `prev` and `pos`
+// (reference lengthOfMatch :592-617), compared 4 bytes per lane per step.
+template <int S>
+__device__ __forceinline__ uint32_t match_length(
+    cgptr in, uint32_t prev, uint32_t pos, uint32_t limit, int lane)
+{
+  cgptr a = in + (size_t)prev * S;
+  cgptr b = in + (size_t)pos * S;
+  const uint32_t limit_bytes = limit * S;
+  for (uint32_t j = 0; j < limit_bytes; j += 4 * kWave) {
+    const uint32_t i = j + 4u * (uint32_t)lane;
+    uint32_t diff_at = 4; // byte index of first difference inside my dword
+    if (i + 4 <= limit_bytes) {
+      const uint32_t x = load_u32_any(a + i) ^ load_u32_any(b + i);
+      if (x)
+        diff_at = (uint32_t)__builtin_ctz(x) >> 3;
+    } else if (i < limit_bytes) {
+      // tail shorter than a dword: byte loads, stop at the limit
+      const uint32_t rem = limit_bytes - i;
+      diff_at = rem; // "mismatch" at the limit ends the search
+      for (uint32_t k = 0; k < rem; ++k)
+        if (a[i + k] != b[i + k]) {
+          diff_at = k;
+          break;
+        }
+    } else {
+      diff_at = 0; // past the limit
+    }
+    const uint64_t m = __ballot(diff_at < 4);
+    if (m) {
+      const int l = __builtin_ctzll(m);
+      const uint32_t byte_idx = j + 4u * (uint32_t)l + read_lane(diff_at, l);
+      const uint32_t mb = byte_idx < limit_bytes ? byte_idx : limit_bytes;
+      return mb / S;
+    }
+  }
+  return limit;
+}
+
+template <int S, bool VERIFY>
+__global__ __launch_bounds__(kWave) void lz4_compress_kernel(
+    const uint8_t* const* __restrict__ in_ptrs,
+    const size_t* __restrict__ in_bytes,
+    uint8_t* const* __restrict__ out_ptrs,
+    size_t* __restrict__ out_bytes,
+    const uint32_t ht_size)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // LDS: [dup slot table: kDupSlots x u32][hash table: ht_size x u16]
+  uint32_t* dup_slots = reinterpret_cast<uint32_t*>(smem);
+  uint16_t* table = reinterpret_cast<uint16_t*>(smem + kDupSlots * 4);
+
+  constexpr uint32_t LVM = (12 + S - 1) / S; // last valid match, elements
+  constexpr uint32_t MEL = (5 + S - 1) / S;  // min ending literals, elements
+  constexpr int INV = 3 / S;                 // lanes without a full 4-byte word
+
+  const int lane = (int)threadIdx.x;
+  const size_t chunk = blockIdx.x;
+  cgptr __restrict__ in = to_global(in_ptrs[chunk]);
+  const uint32_t len = (uint32_t)in_bytes[chunk];
+  gptr __restrict__ out = to_global(out_ptrs[chunk]);
+  const uint32_t L = (len + S - 1) / S;
+  const uint32_t hmask = ht_size - 1;
+
+  // ---- LDS init (reference :815-818 fills the table with NULL_OFFSET)
+  {
+    u32x4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    u32x4* p = reinterpret_cast<u32x4*>(smem);
+    const uint32_t nvec = (kDupSlots * 4 + ((ht_size * 2 + 15) & ~15u)) >> 4;
+    for (uint32_t i = (uint32_t)lane; i < nvec; i += kWave)
+      p[i] = ones;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0); single wave: no barrier
+
+  uint32_t d = 0, c = 0;
+  while (d < L) {
+    const uint32_t token_start = d;
+    for (;;) {
+      if (d + LVM >= L) {
+        // literals to the end of the chunk (reference :832-845)
+        c = write_sequence(out, c, in + (size_t)token_start * S,
+                           len - token_start * S, 0, 0, lane);
+        d = L;
+        break;
+      }
+      int nv = kWave - INV;
+      if ((int)(L - d - LVM) < nv)
+        nv = (int)(L - d - LVM);
+      const bool valid = lane < nv;
+
+      // window word of lane t = the 4 bytes at element d+t (reference
+      // :848-854; for every lane < nv none of them is masked)
+      uint32_t next = 0;
+      if (valid)
+        next = load_u32_any(in + (size_t)(d + (uint32_t)lane) * S);
+      const uint32_t hs = hash_sum(next);
+      const uint32_t hpos = hs & hmask;
+
+      // (B) candidate from earlier windows: table lookup + 4-byte verify
+      // (reference isValidHash :634-663, convertIdx :619-632)
+      uint32_t cand = 0;
+      bool table_hit = false;
+      if (valid) {
+        const uint32_t h = table[hpos];
+        if (h != kNullOffset) {
+          const uint32_t pos = d + (uint32_t)lane;
+          cand = (pos & ~0xFFFFu) + h;
+          if (cand >= pos)
+            cand -= 65536u;
+          if (pos - cand <= 65535u)
+            table_hit = load_u32_any(in + (size_t)cand * S) == next;
+        }
+      }
+
+      // (A) in-window duplicates: lowest lane holding my word.  Every lane
+      // posts its id with ds_min into a slot chosen by its word; the slot
+      // then names the lowest lane of that slot.  If that lane holds my
+      // word it is exactly min{u : next_u == next_t}; otherwise (two words
+      // share a slot) the lane is "unresolved" and settled below.
+      const uint32_t slot = (hs >> 5) & (kDupSlots - 1);
+      if (valid)
+        atomicMin(&dup_slots[slot], (uint32_t)lane);
+      uint32_t w = valid ? dup_slots[slot] : (uint32_t)lane;
+      if (valid)
+        dup_slots[slot] = kDupEmpty;
+      const uint32_t nw = (uint32_t)__shfl((int)next, (int)w);
+      const bool eq = valid && (nw == next);
+      const uint64_t dupmask = __ballot(eq && w != (uint32_t)lane);
+      const uint64_t unres = __ballot(valid && !eq);
+
+      int f = nv;         // first lane with an equal lower lane
+      uint32_t mlane = 0; // that lower lane
+      if (dupmask) {
+        f = __builtin_ctzll(dupmask);
+        mlane = read_lane(w, f);
+      }
+      uint64_t U = unres & low_lanes_mask(f);
+      while (U) {
+        const int u = __builtin_ctzll(U);
+        U &= U - 1;
+        const uint32_t v = read_lane(next, u);
+        const uint64_t m = __ballot(valid && next == v);
+        const int lo = __builtin_ctzll(m);
+        if (lo != u) {
+          f = u;
+          mlane = (uint32_t)lo;
+          break;
+        }
+      }
+      uint32_t match_location = (f < nv) ? d + mlane : L;
+
+      // earliest lane (< f) with a verified table candidate wins
+      // (reference :896-923)
+      const uint64_t tmask = __ballot(table_hit && lane < f);
+      if (tmask) {
+        f = __builtin_ctzll(tmask);
+        match_location = read_lane(cand, f);
+      }
+
+      if (match_location != L) {
+        // reference :925-956
+        insert_window<VERIFY>(table, hpos, d, f, lane);
+        const uint32_t pos = d + (uint32_t)f;
+        const uint32_t off_elems = (pos - match_location) & 0xFFFFu;
+        const uint32_t lit = pos - token_start;
+        const uint32_t ml
+            = match_length<S>(in, match_location, pos, L - pos - MEL, lane);
+        c = write_sequence(out, c, in + (size_t)token_start * S, lit * S,
+                           ml * S, (off_elems * S) & 0xFFFFu, lane);
+        d = token_start + lit + ml;
+        break;
+      }
+      // no match in this window (reference :958-962)
+      insert_window<VERIFY>(table, hpos, d, nv, lane);
+      d += (uint32_t)nv;
+    }
+  }
+  if (lane == 0)
+    out_bytes[chunk] = c;
+}
+
+// --------------------------------------------------------------------------
+// Decoder.  One chunk per wavefront, kDecompWavesPerBlock chunks per
+// workgroup.  All lanes parse the (wave-uniform) token stream; literal runs
+// are 16-byte/lane copies, matches are copied with the reference's
+// `src[i % offset]` rule (coopCopyOverlap :530-555).
+//
+// Deliberate tightening versus the reference (DESIGN.md "LZ4 decoder"):
+// reads of the compressed stream are bounded by comp_len and offset == 0 is
+// rejected; both are undefined behaviour in the reference.
+// --------------------------------------------------------------------------
+constexpr int kDecompWavesPerBlock = 4;
+
+__device__ __forceinline__ bool read_lsic(
+    cgptr comp, uint32_t& c, uint32_t end, uint32_t& num)
+{
+  uint32_t b = 0xff;
+  while (b == 0xff) {
+    if (c >= end)
+      return false;
+    b = comp[c++];
+    num += b;
+  }
+  return true;
+}
+
+template <bool WRITE_OUT>
+__global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_kernel(
+    const uint8_t* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes,
+    const size_t* __restrict__ out_caps,
+    const size_t batch,
+    uint8_t* const* __restrict__ out_ptrs,
+    size_t* __restrict__ actual_bytes,
+    hipcompStatus_t* __restrict__ statuses)
+{
+  const int lane = lane_id();
+  const size_t chunk
+      = (size_t)blockIdx.x * kDecompWavesPerBlock + (threadIdx.x >> 6);
+  if (chunk >= batch)
+    return;
+  cgptr comp = to_global(comp_ptrs[chunk]);
+  const uint32_t end = (uint32_t)comp_bytes[chunk];
+  const uint32_t cap = WRITE_OUT ? (uint32_t)out_caps[chunk] : 0xFFFFFFFFu;
+  gptr out = WRITE_OUT ? to_global(out_ptrs[chunk]) : nullptr;
+
+  uint32_t c = 0, d = 0;
+  bool corrupt = false;
+  while (c < end) {
+    const uint32_t tok = comp[c++];
+    uint32_t lit = tok >> 4;
+    if (lit == 15 && !read_lsic(comp, c, end, lit)) {
+      corrupt = true;
+      break;
+    }
+    if (d + lit > cap || lit > end - c) { // reference :1008
+      corrupt = true;
+      break;
+    }
+    if (WRITE_OUT)
+      wave_copy(out + d, comp + c, lit, lane);
+    c += lit;
+    d += lit;
+    if (c < end) { // reference :1035
+      if (end - c < 2) {
+        corrupt = true;
+        break;
+      }
+      const uint32_t offset = (uint32_t)comp[c] | ((uint32_t)comp[c + 1] << 8);
+      c += 2;
+      uint32_t ml = 4 + (tok & 0x0fu);
+      if ((tok & 0x0fu) == 15 && !read_lsic(comp, c, end, ml)) {
+        corrupt = true;
+        break;
+      }
+      if (d < offset || d + ml > cap || offset == 0) { // reference :1054
+        corrupt = true;
+        break;
+      }
+      if (WRITE_OUT) {
+        // Earlier stores of this wave to out[] are ordered before these
+        // loads (one wave, in-order vector memory, one L1).
+        cgptr src = out + d - offset;
+        gptr dst = out + d;
+        if (offset >= ml) {
+          for (uint32_t i = (uint32_t)lane; i < ml; i += kWave)
+            dst[i] = src[i];
+        } else {
+          for (uint32_t i = (uint32_t)lane; i < ml; i += kWave)
+            dst[i] = src[i % offset];
+        }
+      }
+      d += ml;
+    }
+  }
+  if (lane == 0) {
+    if (actual_bytes)
+      actual_bytes[chunk] = corrupt ? 0 : d; // reference :1088-1096
+    if (WRITE_OUT && statuses)
+      statuses[chunk] = corrupt ? hipcompErrorCannotDecompress : hipcompSuccess;
+  }
+}
+
+} // namespace
+
+// ---- launchers -----------------------------------------------------------
+
+size_t lz4_compress_lds_bytes(uint32_t ht_size)
+{
+  return kDupSlots * 4 + ((ht_size * 2 + 15) & ~15u);
+}
+
+namespace {
+
+template <bool V>
+void launch_compress_t(
+    const uint8_t* const* in_ptrs, const size_t* in_bytes,
+    uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
+    size_t batch, int elem_size, hipStream_t stream)
+{
+  const dim3 grid((unsigned)batch), block(kWave);
+  const size_t lds = lz4_compress_lds_bytes(ht_size);
+  switch (elem_size) {
+  case 1:
+    lz4_compress_kernel<1, V><<<grid, block, lds, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size);
+    break;
+  case 2:
+    lz4_compress_kernel<2, V><<<grid, block, lds, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size);
+    break;
+  default:
+    lz4_compress_kernel<4, V><<<grid, block, lds, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size);
+    break;
+  }
+}
+
+// Whether the LDS same-address store order is verified by read-back (see
+// store_highest_lane_wins).  HIPCOMP_AMD_LZ4_VERIFY_LDS_ORDER=0/1 overrides
+// the built-in default; it exists for the A/B measurement in bench.py and
+// the hardware probe test, not as a user-facing option.
+bool verify_lds_order()
+{
+  static const bool v = [] {
+    const char* e = std::getenv("HIPCOMP_AMD_LZ4_VERIFY_LDS_ORDER");
+    if (e && (e[0] == '0' || e[0] == '1'))
+      return e[0] == '1';
+    return HCAMD_LZ4_VERIFY_LDS_ORDER_DEFAULT;
+  }();
+  return v;
+}
+
+} // namespace
+
+void lz4_launch_compress(
+    const uint8_t* const* in_ptrs, const size_t* in_bytes,
+    uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
+    size_t batch, int elem_size, hipStream_t stream)
+{
+  if (verify_lds_order())
+    launch_compress_t<true>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size,
+                            batch, elem_size, stream);
+  else
+    launch_compress_t<false>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size,
+                             batch, elem_size, stream);
+}
+
+void lz4_launch_decompress(
+    const uint8_t* const* comp_ptrs, const size_t* comp_bytes,
+    const size_t* out_caps, size_t batch, uint8_t* const* out_ptrs,
+    size_t* actual_bytes, hipcompStatus_t* statuses, bool write_out,
+    hipStream_t stream)
+{
+  const dim3 grid((unsigned)((batch + kDecompWavesPerBlock - 1) / kDecompWavesPerBlock));
+  const dim3 block(kWave * kDecompWavesPerBlock);
+  if (write_out)
+    lz4_decompress_kernel<true><<<grid, block, 0, stream>>>(
+        comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
+  else
+    lz4_decompress_kernel<false><<<grid, block, 0, stream>>>(
+        comp_ptrs, comp_bytes, nullptr, batch, nullptr, actual_bytes, nullptr);
+}
+
+} // namespace hcamd

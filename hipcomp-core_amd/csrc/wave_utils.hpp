@@ -1,0 +1,89 @@
+// wave_utils.hpp -- wave64 building blocks shared by the gfx950 codec kernels.
+//
+// Everything here assumes a 64-lane wavefront (CDNA4) and is written for it
+// directly: 64-bit ballots, v_readlane with a scalar lane index, unaligned
+// dword / dwordx4 global accesses (legal on gfx950 in the HSA default
+// unaligned-access mode) and 16-byte-per-lane copies.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace hcamd {
+
+constexpr int kWave = 64;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Chunk buffers are reached through pointers loaded from device arrays, so
+// the compiler cannot tell they are global memory and would emit flat_*
+// accesses (counted on both vmcnt and lgkmcnt).  All data pointers are
+// therefore moved to the global address space explicitly.
+#define HC_GLOBAL __attribute__((address_space(1)))
+typedef HC_GLOBAL uint8_t* gptr;
+typedef const HC_GLOBAL uint8_t* cgptr;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+
+__device__ __forceinline__ gptr to_global(uint8_t* p) { return (gptr)p; }
+__device__ __forceinline__ cgptr to_global(const uint8_t* p) { return (cgptr)p; }
+
+__device__ __forceinline__ uint32_t load_u32_any(cgptr p)
+{
+  return *reinterpret_cast<const HC_GLOBAL u32_unaligned*>(p);
+}
+
+__device__ __forceinline__ u32x4 load_u128_any(cgptr p)
+{
+  return *reinterpret_cast<const HC_GLOBAL u32x4_unaligned*>(p);
+}
+
+__device__ __forceinline__ int lane_id()
+{
+  return (int)(threadIdx.x & (kWave - 1));
+}
+
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane)
+{
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+__device__ __forceinline__ uint64_t low_lanes_mask(int n) // lanes [0, n)
+{
+  return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+}
+
+// Copy n bytes dst <- src with all 64 lanes; any alignment on either side,
+// regions must not overlap.  16-byte aligned stores, unaligned 16-byte loads.
+__device__ __forceinline__ void wave_copy(
+    gptr __restrict__ dst, cgptr __restrict__ src, uint32_t n, int lane)
+{
+  uint32_t head = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
+  if (head > n)
+    head = n;
+  if ((uint32_t)lane < head)
+    dst[lane] = src[lane];
+  dst += head;
+  src += head;
+  n -= head;
+  const uint32_t nvec = n >> 4;
+  uint32_t i = (uint32_t)lane;
+  // 4 x 16 B in flight per lane
+  for (; i + 3 * kWave < nvec; i += 4 * kWave) {
+    u32x4 a = load_u128_any(src + 16u * i);
+    u32x4 b = load_u128_any(src + 16u * (i + kWave));
+    u32x4 c = load_u128_any(src + 16u * (i + 2 * kWave));
+    u32x4 d = load_u128_any(src + 16u * (i + 3 * kWave));
+    *reinterpret_cast<HC_GLOBAL u32x4*>(dst + 16u * i) = a;
+    *reinterpret_cast<HC_GLOBAL u32x4*>(dst + 16u * (i + kWave)) = b;
+    *reinterpret_cast<HC_GLOBAL u32x4*>(dst + 16u * (i + 2 * kWave)) = c;
+    *reinterpret_cast<HC_GLOBAL u32x4*>(dst + 16u * (i + 3 * kWave)) = d;
+  }
+  for (; i < nvec; i += kWave)
+    *reinterpret_cast<HC_GLOBAL u32x4*>(dst + 16u * i) = load_u128_any(src + 16u * i);
+  const uint32_t tail = n & 15u;
+  if ((uint32_t)lane < tail)
+    dst[(nvec << 4) + lane] = src[(nvec << 4) + lane];
+}
+
+} // namespace hcamd

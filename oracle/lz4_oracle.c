@@ -1,0 +1,356 @@
+/*
+ * lz4_oracle.c -- CPU restatement of the reference's batched LZ4 codec.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker.
+ *
+ * Parity pinning: the reference's own tests hold no LZ4 compressed-byte
+ * vectors, so this restatement is pinned against
+ * outputs of the reference itself: oracle/_ref/libhipcomp_ref.so (the
+ * reference's low-level sources compiled unmodified by oracle/Makefile) is
+ * run on the MI355X box by tests/golden/make_golden.py and its compressed
+ * bytes are committed under tests/golden/; tests/test_oracle_golden.py checks
+ * this file against them byte for byte.
+ *
+ * What is restated (all line numbers: /root/reference/src/LZ4Kernels.hiph
+ * unless noted):
+ *   compressStream<T>            :793-969   -> oracle_lz4_compress
+ *   warpMatchAny                 :218-245   (as an exact "lowest equal lane")
+ *   numValidThreadsToMask        :717-720   (int truncation at wave64)
+ *   insertHashTableWarp          :722-741   -> insert_window (quirk rules)
+ *   hash                         :557-561
+ *   convertIdx / isValidHash     :619-663
+ *   lengthOfMatch                :592-617
+ *   token_type/writeSequenceData :280-351, 665-715, writeLSIC :267-278
+ *   decompressStream             :971-1097  -> oracle_lz4_decompress
+ *   maxSizeOfStream              :198-202
+ *   lz4GetHashTableSize          src/lowlevel/LZ4CompressionKernels.hip:142-156
+ *
+ * The reference runs 64 lanes in lock step (ENABLE_HIP_OPT_WARPSIZE64,
+ * CMakeLists.txt:117-121).  Two of its behaviours are not defined by the
+ * C++ source alone and are parameters / documented choices here:
+ *   (1) numValidThreadsToMask returns `int`, and insertHashTableWarp keeps
+ *       the 64-bit match mask in a `const int`: see insert_window().
+ *   (2) several lanes may execute one global_store_short to the same
+ *       address; which lane's value survives is a hardware property
+ *       (`store_winner`: 1 = highest lane, 0 = lowest lane).  Measured on
+ *       MI355X by tests/test_hw_probes.py; the default used everywhere is
+ *       recorded in DESIGN.md.
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+
+#define W 64
+#define NULL_OFFSET 0xFFFFu
+#define MAX_HT 16384u
+
+/* ---- sizes ------------------------------------------------------------ */
+
+/* src/lowlevel/LZ4CompressionKernels.hip:142-156 */
+size_t oracle_lz4_hash_table_size(size_t max_chunk_bytes)
+{
+  size_t p = 1;
+  while (p < max_chunk_bytes)
+    p *= 2;
+  return p < MAX_HT ? p : MAX_HT;
+}
+
+/* LZ4Kernels.hiph:198-202 */
+size_t oracle_lz4_max_compressed_size(size_t n)
+{
+  size_t e = n + 1 + (n + 254) / 255;
+  return (e + 7) / 8 * 8;
+}
+
+/* src/lowlevel/LZ4CompressionKernels.hip:287-296 (0 = error: chunk > 16 MiB) */
+size_t oracle_lz4_compress_temp_size(size_t max_chunk_bytes, size_t batch)
+{
+  return oracle_lz4_hash_table_size(max_chunk_bytes) * 2 * batch;
+}
+
+/* src/lowlevel/LZ4CompressionKernels.hip:298-304 (sizeof(chunk_header)=24) */
+size_t oracle_lz4_decompress_temp_size(size_t num_chunks)
+{
+  return (24 * num_chunks + 7) / 8 * 8;
+}
+
+/* ---- helpers ---------------------------------------------------------- */
+
+static uint32_t brev32(uint32_t v)
+{
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+  v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+  return (v >> 16) | (v << 16);
+}
+
+/* :557-561 */
+static uint32_t lz4_hash(uint32_t key, uint32_t ht_size)
+{
+  return (brev32(key) + (key ^ 0xc375u)) & (ht_size - 1);
+}
+
+static uint32_t load32(const uint8_t* p)
+{
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)
+         | ((uint32_t)p[3] << 24);
+}
+
+/* :267-278 -- returns number of bytes written */
+static uint32_t write_lsic(uint8_t* out, uint32_t number)
+{
+  uint32_t num = number / 255u + 1;
+  for (uint32_t i = 0; i < num; ++i)
+    out[i] = (i + 1 < num) ? 0xFFu : (uint8_t)(number % 255u);
+  return num;
+}
+
+/* :665-715 with token_type :280-351 */
+static uint32_t write_sequence(
+    uint8_t* comp, uint32_t c, const uint8_t* in_bytes, uint32_t lit_start,
+    uint32_t lit_bytes, uint32_t match_bytes, uint16_t offset_bytes)
+{
+  uint8_t lhdr = lit_bytes >= 15 ? 15 : (uint8_t)lit_bytes;
+  /* numMatchesForHeader: uint8_t(num_matches - 4) when < 19, so the final
+   * sequence (num_matches == 0) carries 0xFC & 0x0f = 0xC in its low nibble */
+  uint8_t mhdr = match_bytes >= 19 ? 15 : (uint8_t)(match_bytes - 4);
+  comp[c++] = (uint8_t)(((lhdr & 0x0f) << 4) | (mhdr & 0x0f));
+  if (lit_bytes >= 15)
+    c += write_lsic(comp + c, lit_bytes - 15);
+  memcpy(comp + c, in_bytes + lit_start, lit_bytes);
+  c += lit_bytes;
+  if (match_bytes > 0) {
+    comp[c++] = (uint8_t)(offset_bytes & 0xff);
+    comp[c++] = (uint8_t)(offset_bytes >> 8);
+    if (match_bytes >= 19)
+      c += write_lsic(comp + c, match_bytes - 19);
+  }
+  return c;
+}
+
+/*
+ * insertHashTableWarp (:722-741) as it behaves at wave64.
+ *
+ * For lane t < n the source computes
+ *     const int match = warpMatchAny(numValidThreadsToMask(n), hashPos);
+ *     if (!match || 63 - __clzll(match) == t) table[hashPos] = pos;
+ * numValidThreadsToMask returns int, so for n >= 32 the participants mask is
+ * the sign extension of 0xFFFFFFFF = all 64 lanes; `match` keeps only bits
+ * 0..31 of the equal-hash mask, and __clzll sees its sign extension.
+ * With G = lanes < n sharing lane t's slot, Lo = G & [0,31]:
+ *   n <= 31            : t inserts iff t == max(G)
+ *   n >= 32, t <= 31   : iff 31 not in Lo and t == max(Lo)
+ *   n >= 32, t >= 32   : Lo empty -> inserts (all such lanes of the slot hit
+ *                        the same address in one store instruction; winner =
+ *                        store_winner); 31 in Lo -> iff t == 63; else no.
+ * (lanes >= n read stale LDS in warpMatchAny; they can only set mask bits
+ * >= 32, which the int truncation drops.)
+ */
+static void insert_window(
+    uint16_t* table, const uint32_t* hpos, uint32_t d, int n, int store_winner)
+{
+  for (int t = 0; t < n; ++t) {
+    uint64_t g = 0;
+    for (int u = 0; u < n; ++u)
+      if (hpos[u] == hpos[t])
+        g |= 1ull << u;
+    int ins;
+    if (n <= 31) {
+      ins = (63 - __builtin_clzll(g)) == t;
+    } else {
+      uint32_t lo = (uint32_t)g;
+      if (lo == 0)
+        ins = 1;
+      else if (lo & 0x80000000u)
+        ins = (t == 63);
+      else
+        ins = (31 - __builtin_clz(lo)) == t;
+    }
+    if (!ins)
+      continue;
+    /* Several lanes reach here for one slot only in the "Lo empty" case.
+     * Emulate the one store instruction: winner by store_winner. */
+    if (n >= 32 && t >= 32 && (uint32_t)g == 0) {
+      uint64_t hi = g; /* all inserting lanes of this slot */
+      int win = store_winner ? 63 - __builtin_clzll(hi) : __builtin_ctzll(hi);
+      if (t != win)
+        continue;
+    }
+    table[hpos[t]] = (uint16_t)((d + (uint32_t)t) & 0xFFFFu);
+  }
+}
+
+/* ---- compressor ------------------------------------------------------- */
+
+/*
+ * in/len: one chunk; elem_size in {1,2,4} (hipcompType_t -> T as in
+ * LZ4CompressionKernels.hip:185-219); max_chunk_bytes sizes the hash table
+ * (LZ4CompressionKernels.hip:171).  out must hold
+ * oracle_lz4_max_compressed_size(len).  Returns 0, or -1 on bad arguments.
+ */
+int oracle_lz4_compress(
+    const uint8_t* in, size_t len, int elem_size, size_t max_chunk_bytes,
+    int store_winner, uint8_t* out, size_t* out_len)
+{
+  if (elem_size != 1 && elem_size != 2 && elem_size != 4)
+    return -1;
+  const uint32_t s = (uint32_t)elem_size;
+  const uint32_t H = (uint32_t)oracle_lz4_hash_table_size(max_chunk_bytes);
+  const uint32_t L = (uint32_t)((len + s - 1) / s);      /* :813 */
+  const uint32_t LVM = (12 + s - 1) / s;                 /* :822 */
+  const uint32_t MEL = (5 + s - 1) / s;                  /* :823 */
+  const int INV = (int)(3 / s);                          /* :861 */
+
+  uint16_t* table = (uint16_t*)malloc(sizeof(uint16_t) * H);
+  if (!table)
+    return -1;
+  for (uint32_t i = 0; i < H; ++i)
+    table[i] = NULL_OFFSET;                              /* :815-818 */
+
+  uint32_t d = 0, c = 0;
+  uint32_t next[W], hpos[W];
+
+  while (d < L) {                                        /* :829 */
+    const uint32_t token_start = d;
+    for (;;) {
+      if (d + LVM >= L) {                                /* :832-845 */
+        c = write_sequence(out, c, in, token_start * s,
+                           (uint32_t)len - token_start * s, 0, 0);
+        d = L;
+        break;
+      }
+      /* :863-865 */
+      int nv = W - INV;
+      if ((int)(L - d - LVM) < nv)
+        nv = (int)(L - d - LVM);
+      /* :848-854 -- for every lane < nv the shuffled word equals the four
+       * input bytes at element d+t (none of them is masked: see DESIGN.md) */
+      for (int t = 0; t < nv; ++t) {
+        next[t] = load32(in + (size_t)(d + (uint32_t)t) * s);
+        hpos[t] = lz4_hash(next[t], H);
+      }
+      /* :868-894 local match: first lane with an equal lower lane */
+      int f = nv;
+      uint32_t match_location = L;
+      for (int t = 0; t < nv && f == nv; ++t)
+        for (int u = 0; u < t; ++u)
+          if (next[u] == next[t]) {
+            f = t;
+            match_location = d + (uint32_t)u;
+            break;
+          }
+      /* :896-923 table match for lanes < f (lookups precede this window's
+       * inserts) */
+      for (int t = 0; t < f; ++t) {
+        uint16_t h = table[hpos[t]];
+        if (h == NULL_OFFSET)
+          continue;
+        uint32_t pos = d + (uint32_t)t;
+        uint32_t cand = (pos / 65536u) * 65536u + h;     /* :619-632 */
+        if (cand >= pos)
+          cand -= 65536u;
+        if (pos - cand > 65535u)                         /* :651 */
+          continue;
+        if (load32(in + (size_t)cand * s) != next[t])    /* :656-660 */
+          continue;
+        f = t;
+        match_location = cand;
+        break;
+      }
+      if (match_location != L) {                         /* :925-956 */
+        insert_window(table, hpos, d, f, store_winner);
+        const uint32_t pos = d + (uint32_t)f;
+        const uint16_t off_elems = (uint16_t)(pos - match_location);
+        const uint32_t lit = pos - token_start;
+        /* lengthOfMatch :592-617 */
+        const uint32_t limit = L - pos - MEL;
+        uint32_t ml = 0;
+        while (ml < limit
+               && memcmp(in + (size_t)(match_location + ml) * s,
+                         in + (size_t)(pos + ml) * s, s) == 0)
+          ++ml;
+        c = write_sequence(out, c, in, token_start * s, lit * s, ml * s,
+                           (uint16_t)((uint32_t)off_elems * s));
+        d = token_start + lit + ml;
+        break;
+      }
+      insert_window(table, hpos, d, nv, store_winner);   /* :958-962 */
+      d += (uint32_t)nv;
+    }
+  }
+  free(table);
+  *out_len = c;                                          /* :966-968 */
+  return 0;
+}
+
+/* ---- decompressor ----------------------------------------------------- */
+
+/*
+ * decompressStream :971-1097.  `out` may be NULL for the size-only pass
+ * (lz4BatchGetDecompressSizes: cap = UINT_MAX, nothing written).
+ * Returns the status the reference reports (0 / 12) and *out_len as it
+ * writes it (0 when corrupt).
+ *
+ * Deliberate tightening (documented in DESIGN.md): the reference never
+ * checks reads of the compressed stream against comp_len and never rejects
+ * offset == 0; both are undefined there.  Here a literal run, LSIC or offset
+ * that leaves the stream, and offset == 0, are reported as corrupt.  No
+ * valid LZ4 block is affected.
+ */
+int oracle_lz4_decompress(
+    const uint8_t* comp, size_t comp_len, uint8_t* out, size_t cap,
+    size_t* out_len)
+{
+  const uint32_t end = (uint32_t)comp_len;
+  const uint32_t buf_end = out ? (uint32_t)cap : 0xFFFFFFFFu;
+  uint32_t c = 0, d = 0;
+  int corrupt = 0;
+  while (c < end) {
+    const uint8_t tok = comp[c++];
+    uint32_t lit = tok >> 4;
+    if (lit == 15) {
+      uint8_t b = 0xff;
+      while (b == 0xff) {
+        if (c >= end) { corrupt = 1; break; }
+        b = comp[c++];
+        lit += b;
+      }
+      if (corrupt) break;
+    }
+    if (d + lit > buf_end) { corrupt = 1; break; }       /* :1008 */
+    if (lit > end - c) { corrupt = 1; break; }
+    if (out)
+      memcpy(out + d, comp + c, lit);
+    c += lit;
+    d += lit;
+    if (c < end) {                                       /* :1035 */
+      if (end - c < 2) { corrupt = 1; break; }
+      const uint32_t offset = (uint32_t)comp[c] | ((uint32_t)comp[c + 1] << 8);
+      c += 2;
+      uint32_t ml = 4 + (tok & 0x0f);
+      if ((tok & 0x0f) == 15) {
+        uint8_t b = 0xff;
+        while (b == 0xff) {
+          if (c >= end) { corrupt = 1; break; }
+          b = comp[c++];
+          ml += b;
+        }
+        if (corrupt) break;
+      }
+      if (d < offset || d + ml > buf_end || offset == 0) { /* :1054 */
+        corrupt = 1;
+        break;
+      }
+      if (out)
+        for (uint32_t i = 0; i < ml; ++i)                /* :530-555 */
+          out[d + i] = out[d - offset + i];
+      d += ml;
+    }
+  }
+  *out_len = corrupt ? 0 : d;                            /* :1088-1096 */
+  return corrupt ? 12 : 0;
+}

@@ -1,0 +1,81 @@
+"""ctypes wrapper over oracle/liboracle.so (the C restatements).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_int, c_size_t, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_LIB_PATH = os.path.join(_HERE, "_ref", "libhipcomp_ref.so")
+
+# Which lane's value survives when several lanes of one wave store to the same
+# address in one instruction (1 = highest lane).  Measured on MI355X by
+# tests/test_hw_probes.py; see DESIGN.md.
+STORE_WINNER_HIGHEST = 1
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = ctypes.CDLL(LIB_PATH)
+        L.oracle_lz4_hash_table_size.argtypes = [c_size_t]
+        L.oracle_lz4_hash_table_size.restype = c_size_t
+        L.oracle_lz4_max_compressed_size.argtypes = [c_size_t]
+        L.oracle_lz4_max_compressed_size.restype = c_size_t
+        L.oracle_lz4_compress_temp_size.argtypes = [c_size_t, c_size_t]
+        L.oracle_lz4_compress_temp_size.restype = c_size_t
+        L.oracle_lz4_decompress_temp_size.argtypes = [c_size_t]
+        L.oracle_lz4_decompress_temp_size.restype = c_size_t
+        L.oracle_lz4_compress.argtypes = [c_char_p, c_size_t, c_int, c_size_t, c_int, c_void_p, POINTER(c_size_t)]
+        L.oracle_lz4_compress.restype = c_int
+        L.oracle_lz4_decompress.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t)]
+        L.oracle_lz4_decompress.restype = c_int
+        _lib = L
+    return _lib
+
+
+# ---- LZ4 -------------------------------------------------------------------
+
+def lz4_max_compressed_size(n: int) -> int:
+    return lib().oracle_lz4_max_compressed_size(n)
+
+
+def lz4_hash_table_size(max_chunk: int) -> int:
+    return lib().oracle_lz4_hash_table_size(max_chunk)
+
+
+def lz4_compress(data: bytes, elem_size: int = 1, max_chunk_bytes: int | None = None,
+                 store_winner: int = STORE_WINNER_HIGHEST) -> bytes:
+    if max_chunk_bytes is None:
+        max_chunk_bytes = len(data)
+    cap = lz4_max_compressed_size(len(data)) + 16
+    out = ctypes.create_string_buffer(cap)
+    n = c_size_t(0)
+    rc = lib().oracle_lz4_compress(data, len(data), elem_size, max_chunk_bytes, store_winner,
+                                   ctypes.cast(out, c_void_p), ctypes.byref(n))
+    if rc != 0:
+        raise ValueError("oracle_lz4_compress: bad arguments")
+    return out.raw[: n.value]
+
+
+def lz4_decompress(comp: bytes, capacity: int):
+    """-> (status, bytes).  status 0 / 12 as the reference reports it."""
+    out = ctypes.create_string_buffer(max(capacity, 1))
+    n = c_size_t(0)
+    st = lib().oracle_lz4_decompress(comp, len(comp), ctypes.cast(out, c_void_p), capacity, ctypes.byref(n))
+    return st, out.raw[: n.value]
+
+
+def lz4_decompressed_size(comp: bytes):
+    """Size-only pass (reference lz4BatchGetDecompressSizes)."""
+    n = c_size_t(0)
+    st = lib().oracle_lz4_decompress(comp, len(comp), None, 0, ctypes.byref(n))
+    return st, n.value

@@ -1,0 +1,46 @@
+// hw_probes.hip -- tiny kernels that measure hardware-defined behaviour the
+// bit-exact LZ4 path depends on.  Test
+// infrastructure: built into tests/probes/libhwprobes.so by
+// __graft_entry__.build(), loaded only by tests/test_hw_probes.py.
+//
+//  (1) several lanes of one wave execute ONE global_store_short to the same
+//      address: which lane's value survives?  (the reference's
+//      insertHashTableWarp does this, src/LZ4Kernels.hiph:734-737)
+//  (2) the same for ONE ds_write_b16 (this library keeps the table in LDS).
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+__global__ void k_global_store_short(uint16_t* out, const int* slot, unsigned long long mask)
+{
+  const int t = threadIdx.x;
+  const int s = slot[t];
+  if ((mask >> t) & 1ull)
+    out[s] = (uint16_t)(1000 + t);
+}
+
+__global__ void k_lds_store_short(uint16_t* out, const int* slot, unsigned long long mask, int nslots)
+{
+  extern __shared__ uint16_t tab[];
+  const int t = threadIdx.x;
+  for (int i = t; i < nslots; i += 64)
+    tab[i] = 0xFFFF;
+  __syncthreads();
+  const int s = slot[t];
+  if ((mask >> t) & 1ull)
+    tab[s] = (uint16_t)(1000 + t);
+  __syncthreads();
+  for (int i = t; i < nslots; i += 64)
+    out[i] = tab[i];
+}
+
+extern "C" int probe_global_store_short(uint16_t* out, const int* slot, unsigned long long mask, hipStream_t st)
+{
+  k_global_store_short<<<1, 64, 0, st>>>(out, slot, mask);
+  return (int)hipGetLastError();
+}
+
+extern "C" int probe_lds_store_short(uint16_t* out, const int* slot, unsigned long long mask, int nslots, hipStream_t st)
+{
+  k_lds_store_short<<<1, 64, nslots * 2, st>>>(out, slot, mask, nslots);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports
+every symbol include/hipcomp/*.h declares (and nothing else), and the pure
+host size queries follow the reference's formulas."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    for h in ("lz4.h", "snappy.h", "cascaded.h"):
+        text = open(os.path.join(ROOT, "include", "hipcomp", h)).read()
+        names |= set(re.findall(r"hipcompStatus_t\s+(hipcompBatched\w+)\s*\(", text))
+    return names
+
+
+def test_library_exports_exactly_the_declared_abi(hc):
+    lib = hc.default_library()
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.path], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    declared = _declared_symbols()
+    built = {s for s in declared if any(s.startswith(f"hipcompBatched{c}") for c in lib.codecs)}
+    assert built <= exported, sorted(built - exported)
+    assert exported <= declared, sorted(exported - declared)
+    assert len(declared) == 18
+
+
+def test_headers_compile_as_c(tmp_path):
+    """The public headers are C-clean (the reference proves this with its C harness)."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "hipcomp/lz4.h"\n#include "hipcomp/snappy.h"\n#include "hipcomp/cascaded.h"\n'
+                   "int main(void){hipcompBatchedLZ4Opts_t o = hipcompBatchedLZ4DefaultOpts;"
+                   "hipcompBatchedCascadedOpts_t c = hipcompBatchedCascadedDefaultOpts;"
+                   "hipcompBatchedSnappyOpts_t s = hipcompBatchedSnappyDefaultOpts;"
+                   "return (int)o.data_type + c.num_RLEs - 2 + s.reserved;}\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                        "-I", "/opt/rocm/include", "-c", str(src), "-o", str(tmp_path / "t.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.parametrize("n", [0, 1, 100, 255, 256, 65535, 65536, 1 << 20, 1 << 24])
+def test_lz4_size_queries(hc, oracle, n):
+    lib = hc.default_library()
+    opts = hc.LZ4Opts(hc.hipcompType.CHAR)
+    assert lib.max_output_chunk_size("LZ4", n, opts) == (n + 1 + (n + 254) // 255 + 7) // 8 * 8
+    assert lib.max_output_chunk_size("LZ4", n, opts) == oracle.lz4_max_compressed_size(n)
+    ht = 1
+    while ht < n:
+        ht *= 2
+    ht = min(ht, 16384)
+    assert oracle.lz4_hash_table_size(n) == ht
+    for batch in (1, 7, 100000):
+        assert lib.compress_temp_size("LZ4", batch, n, opts) == ht * 2 * batch
+        assert lib.decompress_temp_size("LZ4", batch, n) == (24 * batch + 7) // 8 * 8
+
+
+def test_lz4_size_query_errors(hc):
+    lib = hc.default_library()
+    out = ctypes.c_size_t(0)
+    opts = hc.LZ4Opts(0)
+    assert lib.hipcompBatchedLZ4CompressGetTempSize(1, (1 << 24) + 1, opts, ctypes.byref(out)) == 10
+    assert lib.hipcompBatchedLZ4CompressGetMaxOutputChunkSize((1 << 24) + 1, opts, ctypes.byref(out)) == 10
+    assert lib.hipcompBatchedLZ4CompressGetTempSize(1, 100, opts, None) == 10
+    assert lib.hipcompBatchedLZ4CompressGetMaxOutputChunkSize(100, opts, None) == 10
+    assert lib.hipcompBatchedLZ4DecompressGetTempSize(1, 100, None) == 10
+    assert lib.hipcompBatchedLZ4GetDecompressSizeAsync(None, None, None, 1, None) == 10
+    # 65536-byte chunks: the numbers SURVEY.md 8(a) L1/L2 quote
+    assert lib.compress_temp_size("LZ4", 100000, 65536, opts) == 3276800000
+    assert lib.max_output_chunk_size("LZ4", 65536, opts) == 65800

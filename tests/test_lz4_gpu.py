@@ -1,0 +1,171 @@
+"""LZ4 parity on the GPU, through the C ABI: compressed bytes vs the CPU
+oracle and vs the reference's own build (oracle/_ref, when present), round
+trips, the reference harness's batches and its error-path checks
+(reference tests/test_batch_c_api.h:225-790)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import datagen
+
+pytestmark = pytest.mark.gpu
+
+TYPES = [("CHAR", 0, 1), ("USHORT", 3, 2), ("INT", 4, 4)]
+
+
+def _compress_both(hc, reflib, chunks, dtype, max_chunk):
+    import torch
+    src = hc.batch.from_host_chunks(chunks, "cuda:0")
+    mine = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype)).compress(src, max_chunk)
+    torch.cuda.synchronize()
+    ref = None
+    if reflib is not None:
+        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=reflib).compress(src, max_chunk)
+        torch.cuda.synchronize()
+    return src, mine, ref
+
+
+@pytest.mark.parametrize("tname,dtype,es", TYPES)
+def test_edge_chunks_bit_exact(hc, oracle, reflib, cuda, tname, dtype, es):
+    named = datagen.edge_chunks()
+    # typed modes need sizeof(T)-aligned starts (true: 16-B stride) -- any length is legal
+    chunks = [c for _, c in named]
+    for max_chunk in (65536, 0, 1000):
+        src, mine, ref = _compress_both(hc, reflib, chunks, dtype, max_chunk)
+        got = mine.to_host_chunks()
+        refgot = ref.to_host_chunks() if ref is not None else None
+        for i, (name, c) in enumerate(named):
+            want = oracle.lz4_compress(c, es, max_chunk)
+            assert got[i] == want, f"{name} {tname} max_chunk={max_chunk}: kernel != oracle"
+            if refgot is not None:
+                assert refgot[i] == want, f"{name} {tname} max_chunk={max_chunk}: oracle != reference"
+        # round trip through my decoder
+        codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
+        dec, actual, statuses = codec.decompress(mine, 65536)
+        assert statuses.cpu().tolist() == [0] * len(chunks)
+        assert dec.to_host_chunks() == chunks
+        assert codec.get_decompress_size(mine).cpu().tolist() == [len(c) for c in chunks]
+
+
+def test_large_u8_chunk_beyond_64k_elements(hc, oracle, reflib, cuda):
+    """> 65536 elements: exercises the 16-bit position wrap of the hash table."""
+    rng = np.random.default_rng(5)
+    base = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))
+    chunks = [(base * 100)[:250000], datagen.text_like(3, 200001), bytes(rng.integers(0, 3, 150000, dtype=np.uint8))]
+    for dtype, es in ((0, 1), (4, 4)):
+        src, mine, ref = _compress_both(hc, reflib, chunks, dtype, 250000)
+        got = mine.to_host_chunks()
+        for i, c in enumerate(chunks):
+            want = oracle.lz4_compress(c, es, 250000)
+            assert got[i] == want
+            if ref is not None:
+                assert ref.to_host_chunks()[i] == want
+        dec, actual, statuses = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype)).decompress(mine, 250016)
+        assert dec.to_host_chunks() == chunks
+
+
+def test_reference_harness_batches(hc, oracle, reflib, cuda):
+    """The six batches of tests/test_batch_c_api.h:772-777 with its data."""
+    import torch
+    for chunks in datagen.harness_batches():
+        max_chunk = max(len(c) for c in chunks)
+        for dtype, es in ((0, 1), (4, 4)):
+            src, mine, ref = _compress_both(hc, reflib, chunks, dtype, max_chunk)
+            got = mine.to_host_chunks()
+            if ref is not None:
+                assert got == ref.to_host_chunks(), "kernel != reference build"
+            step = max(1, len(chunks) // 64)  # oracle on a sample (the reference build covers all)
+            for i in range(0, len(chunks), step):
+                assert got[i] == oracle.lz4_compress(chunks[i], es, max_chunk)
+            codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
+            # GetDecompressSize == input bytes (harness :366-384)
+            assert codec.get_decompress_size(mine).cpu().tolist() == [len(c) for c in chunks]
+            dec, actual, statuses = codec.decompress(mine, max_chunk)
+            assert statuses.cpu().tolist() == [0] * len(chunks)       # harness :456-458
+            assert actual.cpu().tolist() == [len(c) for c in chunks]
+            assert dec.to_host_chunks() == chunks
+            # nullptr actual_bytes / statuses accepted (harness :399-426)
+            dec2, a2, s2 = codec.decompress(mine, max_chunk, with_status=False)
+            torch.cuda.synchronize()
+            dec2.sizes = src.sizes
+            assert dec2.to_host_chunks() == chunks
+
+
+def test_crash_safe_raw_input_is_rejected(hc, cuda):
+    """Decompressing raw input as if it were compressed (harness :505-724):
+    every chunk -> hipcompErrorCannotDecompress and size 0."""
+    chunks = next(iter(b for b in datagen.harness_batches() if len(b) == 127))
+    src = hc.batch.from_host_chunks(chunks, "cuda:0")
+    codec = hc.batch.Codec("LZ4")
+    dec, actual, statuses = codec.decompress(src, max(len(c) for c in chunks))
+    assert statuses.cpu().tolist() == [hc.hipcompStatus.ErrorCannotDecompress] * len(chunks)
+    assert actual.cpu().tolist() == [0] * len(chunks)
+
+
+def test_decoder_error_paths_match_oracle(hc, oracle, cuda):
+    rng = np.random.default_rng(77)
+    data = datagen.text_like(5, 30000)
+    good = oracle.lz4_compress(data, 1, 65536)
+    streams = [good, good[:-1], good[: len(good) // 2], good[:1], b"\xf0", b"\x10A\x00\x00", b"\x1fA\x01\x00",
+               bytes(rng.integers(0, 256, 500, dtype=np.uint8)), b"", b"\x00"]
+    for cap in (30000, 29999, 100):
+        comp = hc.batch.from_host_chunks(streams, "cuda:0")
+        dec, actual, statuses = hc.batch.Codec("LZ4").decompress(comp, cap)
+        st = statuses.cpu().tolist()
+        ac = actual.cpu().tolist()
+        for i, s in enumerate(streams):
+            ost, obytes = oracle.lz4_decompress(s, cap)
+            assert st[i] == ost, (i, cap)
+            assert ac[i] == len(obytes), (i, cap)
+            if ost == 0:
+                assert dec.chunk_bytes(i, ac[i]) == obytes
+
+
+def test_decodes_liblz4_streams(hc, cuda):
+    """Streams from the system liblz4 (a different, valid encoder) decode."""
+    try:
+        lz4 = ctypes.CDLL("liblz4.so.1")
+    except OSError:
+        pytest.skip("liblz4.so.1 not on this box")
+    lz4.LZ4_compress_default.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    lz4.LZ4_compressBound.argtypes = [ctypes.c_int]
+    chunks = [c for _, c in datagen.edge_chunks() if len(c) > 0]
+    comp = []
+    for c in chunks:
+        cap = lz4.LZ4_compressBound(len(c))
+        buf = ctypes.create_string_buffer(cap)
+        n = lz4.LZ4_compress_default(c, buf, len(c), cap)
+        assert n > 0
+        comp.append(buf.raw[:n])
+    cb = hc.batch.from_host_chunks(comp, "cuda:0")
+    codec = hc.batch.Codec("LZ4")
+    dec, actual, statuses = codec.decompress(cb, 65536)
+    assert statuses.cpu().tolist() == [0] * len(chunks)
+    assert dec.to_host_chunks() == chunks
+    assert codec.get_decompress_size(cb).cpu().tolist() == [len(c) for c in chunks]
+
+
+def test_host_side_errors(hc, cuda):
+    import torch
+    lib = hc.default_library()
+    src = hc.batch.from_host_chunks([b"abc" * 100], "cuda:0")
+    codec = hc.batch.Codec("LZ4")
+    dst = hc.batch.alloc_batch(1, codec.max_output_chunk_size(300), "cuda:0")
+    small = torch.empty(8, dtype=torch.uint8, device="cuda:0")
+    # temp too small -> InvalidValue (reference LZ4CompressionKernels.hip:173-180)
+    assert codec.compress_async(src, 65536, small, dst) == hc.hipcompStatus.ErrorInvalidValue
+    # LONGLONG unsupported (reference :217-218)
+    big = torch.empty(32768, dtype=torch.uint8, device="cuda:0")
+    bad = hc.batch.Codec("LZ4", hc.LZ4Opts(hc.hipcompType.LONGLONG))
+    assert bad.compress_async(src, 65536, big, dst) == hc.hipcompStatus.ErrorInvalidValue
+    # host pointer array -> InvalidValue (reference HipUtils.hip:91-108)
+    hostptrs = (ctypes.c_void_p * 1)(src.data.data_ptr())
+    st = lib.hipcompBatchedLZ4CompressAsync(ctypes.addressof(hostptrs), src.sizes.data_ptr(), 65536, 1,
+                                            big.data_ptr(), big.numel(), dst.ptrs.data_ptr(), dst.sizes.data_ptr(),
+                                            hc.LZ4Opts(0), None)
+    assert st == hc.hipcompStatus.ErrorInvalidValue
+    # chunk > 16 MiB
+    out = ctypes.c_size_t(0)
+    assert lib.hipcompBatchedLZ4CompressGetTempSize(1, (1 << 24) + 1, hc.LZ4Opts(0), ctypes.byref(out)) == 10
+    assert lib.hipcompBatchedLZ4CompressGetMaxOutputChunkSize((1 << 24) + 1, hc.LZ4Opts(0), ctypes.byref(out)) == 10

@@ -152,9 +152,14 @@ class Codec:
 
     # -- convenience (allocates like a caller of the C API would) ----------
     def compress(self, src: ChunkBatch, max_chunk: Optional[int] = None) -> ChunkBatch:
+        """``max_chunk`` is the value handed to the C API as
+        max_uncompressed_chunk_bytes (for LZ4 it sizes the hash table and so
+        takes part in the result); output buffers are always sized from the
+        real largest chunk."""
+        real_max = int(src.sizes.max().item()) if src.n else 0
         if max_chunk is None:
-            max_chunk = int(src.sizes.max().item()) if src.n else 0
-        dst = alloc_batch(src.n, self.max_output_chunk_size(max_chunk), src.device)
+            max_chunk = real_max
+        dst = alloc_batch(src.n, self.max_output_chunk_size(max(real_max, max_chunk)), src.device)
         tbytes = self.compress_temp_size(src.n, max_chunk)
         temp = torch.empty(max(tbytes, 8), dtype=torch.uint8, device=src.device)
         _check(self.compress_async(src, max_chunk, temp, dst), f"hipcompBatched{self.name}CompressAsync")

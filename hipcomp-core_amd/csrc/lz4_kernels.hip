@@ -13,9 +13,9 @@
 //                                           table + one ds_bpermute, exact
 //                                           fallback only for colliding lanes
 //   second warpMatchAny for the insert      insert rule (incl. the wave64
-//   (:722-741)                              `int` truncation)
-//                                           expressed as two ordered masked
-//                                           LDS stores, highest lane wins
+//   (:722-741) + hardware arbitration of    `int` truncation)
+//   same-address global_store_short         expressed as two ordered masked
+//                                           LDS stores (see insert_window)
 //   shuffleLiterals (:754-791)              one unaligned dword load per lane
 //   1 byte/lane literal + match compare     16-byte/lane copies, 4-byte/lane
 //                                           match-length compare
@@ -28,11 +28,6 @@
 #include "lz4_launch.hpp"
 #include "wave_utils.hpp"
 
-#include <cstdlib>
-
-#ifndef HCAMD_LZ4_VERIFY_LDS_ORDER_DEFAULT
-#define HCAMD_LZ4_VERIFY_LDS_ORDER_DEFAULT true
-#endif
 
 namespace hcamd {
 
@@ -88,55 +83,70 @@ __device__ __forceinline__ uint32_t write_sequence(
   return c;
 }
 
-// Masked LDS store of this window's positions where, for lanes that share a
-// slot, the HIGHEST lane's value must survive.  The hardware's own
-// same-address resolution inside one ds_write_b16 is not architecturally
-// documented, so the store is verified by reading back and re-issued by any
-// higher lane that lost (one pass when the hardware already keeps the
-// highest lane -- measured so on MI355X, tests/test_hw_probes.py).
-template <bool VERIFY>
-__device__ __forceinline__ void store_highest_lane_wins(
-    uint16_t* table, uint32_t hpos, uint32_t d, int lane, bool active)
+// ---------------------------------------------------------------------------
+// Hash-table insert for lanes [0, n) of the window at element position d,
+// reproducing what the reference's insertHashTableWarp (:722-741) does when
+// it runs 64 lanes wide:
+//   n <= 31: per slot the highest lane's position is stored;
+//   n >= 32: numValidThreadsToMask (:717-720) returns `int` and the 64-bit
+//            match mask is kept in a `const int`, so
+//            - a slot shared with lane 31 is left alone, except that lane 63
+//              stores if it is in that slot;
+//            - otherwise the highest lane among lanes 0..30 of the slot
+//              stores;
+//            - a slot that holds only lanes >= 32: they ALL execute the same
+//              global_store_short and the hardware picks the survivor.
+//              Measured on MI355X (tests/test_hw_probes.py): the lanes of a
+//              wave are written in the order  for g in 0..3, for p in 3..0,
+//              for q in 0..3: lane 16g+4q+p,  last write survives.
+//
+// Mechanism here: ds_write_b16 keeps the HIGHEST lane among lanes that hit
+// one address (measured, same test), so
+//   store 1: lanes >= 32, with the lanes permuted (ds_bpermute) so that lane
+//            order equals the hardware's write order above;
+//   store 2: lanes 0..30 (not in lane 31's slot), natural order -- it
+//            overrides store 1 wherever a slot has a lane below 32.
+// ---------------------------------------------------------------------------
+struct InsertPerm
 {
-  const uint16_t val = (uint16_t)((d + (uint32_t)lane) & 0xFFFFu);
-  if (!VERIFY) {
-    if (active)
-      table[hpos] = val;
-    return;
+  uint32_t src_lane;  // lane whose (slot,position) this lane stores in store 1
+  uint32_t src_addr4; // 4 * src_lane (ds_bpermute byte address)
+};
+
+__device__ __forceinline__ InsertPerm make_insert_perm(int lane)
+{
+  InsertPerm p;
+  if (lane < 32) {
+    p.src_lane = (uint32_t)lane;
+  } else {
+    const uint32_t r = (uint32_t)lane - 32u;
+    p.src_lane = 32u + (r & 16u) + 4u * (r & 3u) + (3u - ((r >> 2) & 3u));
   }
-  while (__ballot(active)) {
-    if (active)
-      table[hpos] = val;
-    uint32_t rb = active ? (uint32_t)table[hpos] : 0u;
-    // lane that produced rb: window positions are consecutive mod 65536
-    const uint32_t rb_lane = (rb - d) & 0xFFFFu;
-    active = active && (rb_lane < (uint32_t)lane);
-  }
+  p.src_addr4 = p.src_lane * 4u;
+  return p;
 }
 
-// Hash-table insert for lanes [0, n) of the window at element position d,
-// with the reference's wave64 behaviour (reference
-// insertHashTableWarp :722-741, numValidThreadsToMask :717-720):
-//   n <= 31: per slot the highest lane's position is stored;
-//   n >= 32: a slot shared with lane 31 is left alone, except that lane 63
-//            stores if it is in that slot; otherwise the highest lane among
-//            lanes 0..30 of the slot stores; if the slot holds only lanes
-//            >= 32 they all store in one instruction and the hardware keeps
-//            the highest lane (HW_STORE_WINNER_HIGHEST, probed).
-template <bool VERIFY>
 __device__ __forceinline__ void insert_window(
-    uint16_t* table, uint32_t hpos, uint32_t d, int n, int lane)
+    uint16_t* table, uint32_t hpos, uint32_t d, int n, int lane,
+    const InsertPerm& perm)
 {
   if (n <= 31) {
-    store_highest_lane_wins<VERIFY>(table, hpos, d, lane, lane < n);
+    if (lane < n)
+      table[hpos] = (uint16_t)((d + (uint32_t)lane) & 0xFFFFu);
     return;
   }
   const uint32_t h31 = read_lane(hpos, 31);
   const bool in31 = (hpos == h31);
   const bool hi = lane >= 32 && lane < n && (!in31 || lane == 63);
-  const bool lo = lane < 31 && !in31;
-  store_highest_lane_wins<VERIFY>(table, hpos, d, lane, hi);
-  store_highest_lane_wins<VERIFY>(table, hpos, d, lane, lo);
+  // store 1 (permuted): bit 31 carries the "this lane stores" flag
+  const uint32_t packed = hpos | (hi ? 0x80000000u : 0u);
+  const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(
+      (int)perm.src_addr4, (int)packed);
+  if (lane >= 32 && (got & 0x80000000u))
+    table[got & 0x7FFFFFFFu] = (uint16_t)((d + perm.src_lane) & 0xFFFFu);
+  // store 2
+  if (lane < 31 && !in31)
+    table[hpos] = (uint16_t)((d + (uint32_t)lane) & 0xFFFFu);
 }
 
 // First mismatching element between the strings at elements `prev` and `pos`
@@ -178,7 +188,7 @@ __device__ __forceinline__ uint32_t match_length(
   return limit;
 }
 
-template <int S, bool VERIFY>
+template <int S>
 __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
     const uint8_t* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
@@ -202,6 +212,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
   gptr __restrict__ out = to_global(out_ptrs[chunk]);
   const uint32_t L = (len + S - 1) / S;
   const uint32_t hmask = ht_size - 1;
+  const InsertPerm perm = make_insert_perm(lane);
 
   // ---- LDS init (reference :815-818 fills the table with NULL_OFFSET)
   {
@@ -248,7 +259,14 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
           cand = (pos & ~0xFFFFu) + h;
           if (cand >= pos)
             cand -= 65536u;
-          if (pos - cand <= 65535u)
+          // The reference accepts any candidate within 65535 ELEMENTS and
+          // then truncates the byte offset to 16 bits (:651, :954), which
+          // corrupts typed-mode (S > 1) streams of chunks larger than 64 KiB.
+          // Candidates whose byte distance does not fit are rejected here;
+          // for chunks <= 64 KiB this never triggers, so those stay
+          // bit-identical (DESIGN.md "deliberate deviations").
+          const uint32_t dist = pos - cand;
+          if (dist <= 65535u && dist * S <= 65535u)
             table_hit = load_u32_any(in + (size_t)cand * S) == next;
         }
       }
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
 
       if (match_location != L) {
         // reference :925-956
-        insert_window<VERIFY>(table, hpos, d, f, lane);
+        insert_window(table, hpos, d, f, lane, perm);
         const uint32_t pos = d + (uint32_t)f;
         const uint32_t off_elems = (pos - match_location) & 0xFFFFu;
         const uint32_t lit = pos - token_start;
@@ -312,7 +330,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
         break;
       }
       // no match in this window (reference :958-962)
-      insert_window<VERIFY>(table, hpos, d, nv, lane);
+      insert_window(table, hpos, d, nv, lane, perm);
       d += (uint32_t)nv;
     }
   }
@@ -431,10 +449,7 @@ size_t lz4_compress_lds_bytes(uint32_t ht_size)
   return kDupSlots * 4 + ((ht_size * 2 + 15) & ~15u);
 }
 
-namespace {
-
-template <bool V>
-void launch_compress_t(
+void lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
     size_t batch, int elem_size, hipStream_t stream)
@@ -443,48 +458,18 @@ void launch_compress_t(
   const size_t lds = lz4_compress_lds_bytes(ht_size);
   switch (elem_size) {
   case 1:
-    lz4_compress_kernel<1, V><<<grid, block, lds, stream>>>(
+    lz4_compress_kernel<1><<<grid, block, lds, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size);
     break;
   case 2:
-    lz4_compress_kernel<2, V><<<grid, block, lds, stream>>>(
+    lz4_compress_kernel<2><<<grid, block, lds, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size);
     break;
   default:
-    lz4_compress_kernel<4, V><<<grid, block, lds, stream>>>(
+    lz4_compress_kernel<4><<<grid, block, lds, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size);
     break;
   }
-}
-
-// Whether the LDS same-address store order is verified by read-back (see
-// store_highest_lane_wins).  HIPCOMP_AMD_LZ4_VERIFY_LDS_ORDER=0/1 overrides
-// the built-in default; it exists for the A/B measurement in bench.py and
-// the hardware probe test, not as a user-facing option.
-bool verify_lds_order()
-{
-  static const bool v = [] {
-    const char* e = std::getenv("HIPCOMP_AMD_LZ4_VERIFY_LDS_ORDER");
-    if (e && (e[0] == '0' || e[0] == '1'))
-      return e[0] == '1';
-    return HCAMD_LZ4_VERIFY_LDS_ORDER_DEFAULT;
-  }();
-  return v;
-}
-
-} // namespace
-
-void lz4_launch_compress(
-    const uint8_t* const* in_ptrs, const size_t* in_bytes,
-    uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, hipStream_t stream)
-{
-  if (verify_lds_order())
-    launch_compress_t<true>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size,
-                            batch, elem_size, stream);
-  else
-    launch_compress_t<false>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size,
-                             batch, elem_size, stream);
 }
 
 void lz4_launch_decompress(

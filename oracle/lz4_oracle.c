@@ -34,9 +34,11 @@
  *       the 64-bit match mask in a `const int`: see insert_window().
  *   (2) several lanes may execute one global_store_short to the same
  *       address; which lane's value survives is a hardware property
- *       (`store_winner`: 1 = highest lane, 0 = lowest lane).  Measured on
- *       MI355X by tests/test_hw_probes.py; the default used everywhere is
- *       recorded in DESIGN.md.
+ *       (`store_winner`: 0 = lowest lane, 1 = highest lane, 2 = the order
+ *       measured on MI355X/gfx950 by tests/test_hw_probes.py: the wave's
+ *       lanes are written in the order  for g in 0..3, for p in 3..0, for q
+ *       in 0..3: lane 16g+4q+p  and the last write survives).  2 is the
+ *       default used everywhere (DESIGN.md "hardware-defined behaviour").
  */
 #include <stddef.h>
 #include <stdint.h>
@@ -176,7 +178,23 @@ static void insert_window(
      * Emulate the one store instruction: winner by store_winner. */
     if (n >= 32 && t >= 32 && (uint32_t)g == 0) {
       uint64_t hi = g; /* all inserting lanes of this slot */
-      int win = store_winner ? 63 - __builtin_clzll(hi) : __builtin_ctzll(hi);
+      int win;
+      if (store_winner == 0) {
+        win = __builtin_ctzll(hi);
+      } else if (store_winner == 1) {
+        win = 63 - __builtin_clzll(hi);
+      } else {
+        int best = -1;
+        win = -1;
+        for (int u = 32; u < 64; ++u)
+          if ((hi >> u) & 1) {
+            int key = ((u >> 4) << 4) | ((3 - (u & 3)) << 2) | ((u >> 2) & 3);
+            if (key > best) {
+              best = key;
+              win = u;
+            }
+          }
+      }
       if (t != win)
         continue;
     }
@@ -187,14 +205,16 @@ static void insert_window(
 /* ---- compressor ------------------------------------------------------- */
 
 /*
+ * valid_offsets = 0 restates the reference exactly; 1 is what the product
+ * does (identical for every chunk <= 64 KiB; see the comment at the check).
  * in/len: one chunk; elem_size in {1,2,4} (hipcompType_t -> T as in
  * LZ4CompressionKernels.hip:185-219); max_chunk_bytes sizes the hash table
  * (LZ4CompressionKernels.hip:171).  out must hold
  * oracle_lz4_max_compressed_size(len).  Returns 0, or -1 on bad arguments.
  */
-int oracle_lz4_compress(
+int oracle_lz4_compress_ex(
     const uint8_t* in, size_t len, int elem_size, size_t max_chunk_bytes,
-    int store_winner, uint8_t* out, size_t* out_len)
+    int store_winner, int valid_offsets, uint8_t* out, size_t* out_len)
 {
   if (elem_size != 1 && elem_size != 2 && elem_size != 4)
     return -1;
@@ -255,6 +275,13 @@ int oracle_lz4_compress(
           cand -= 65536u;
         if (pos - cand > 65535u)                         /* :651 */
           continue;
+        /* valid_offsets: the product's one deliberate deviation.  The
+         * reference truncates offset_elems * s to 16 bits (:954), so in typed
+         * modes a match farther than 65535 BYTES yields a corrupt stream
+         * (only possible for chunks > 64 KiB).  With valid_offsets such a
+         * candidate is rejected instead. */
+        if (valid_offsets && (pos - cand) * s > 65535u)
+          continue;
         if (load32(in + (size_t)cand * s) != next[t])    /* :656-660 */
           continue;
         f = t;
@@ -285,6 +312,15 @@ int oracle_lz4_compress(
   free(table);
   *out_len = c;                                          /* :966-968 */
   return 0;
+}
+
+/* Reference-faithful form (valid_offsets = 0). */
+int oracle_lz4_compress(
+    const uint8_t* in, size_t len, int elem_size, size_t max_chunk_bytes,
+    int store_winner, uint8_t* out, size_t* out_len)
+{
+  return oracle_lz4_compress_ex(in, len, elem_size, max_chunk_bytes,
+                                store_winner, 0, out, out_len);
 }
 
 /* ---- decompressor ----------------------------------------------------- */

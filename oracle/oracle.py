@@ -12,10 +12,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboracle.so")
 REF_LIB_PATH = os.path.join(_HERE, "_ref", "libhipcomp_ref.so")
 
-# Which lane's value survives when several lanes of one wave store to the same
-# address in one instruction (1 = highest lane).  Measured on MI355X by
-# tests/test_hw_probes.py; see DESIGN.md.
-STORE_WINNER_HIGHEST = 1
+# Which lane's value survives when several lanes of one wave execute ONE
+# global_store_short to the same address (0 = lowest lane, 1 = highest lane,
+# 2 = the order measured on MI355X by tests/test_hw_probes.py: last write in
+# the sequence "for g in 0..3, for p in 3..0, for q in 0..3: lane 16g+4q+p").
+STORE_WINNER_GFX950 = 2
+
+
+def gfx950_store_order_key(lane: int):
+    """Sort key: the lane with the largest key survives (measured, gfx950)."""
+    return (lane >> 4, 3 - (lane & 3), (lane >> 2) & 3)
 
 _lib = None
 
@@ -34,8 +40,9 @@ def lib():
         L.oracle_lz4_compress_temp_size.restype = c_size_t
         L.oracle_lz4_decompress_temp_size.argtypes = [c_size_t]
         L.oracle_lz4_decompress_temp_size.restype = c_size_t
-        L.oracle_lz4_compress.argtypes = [c_char_p, c_size_t, c_int, c_size_t, c_int, c_void_p, POINTER(c_size_t)]
-        L.oracle_lz4_compress.restype = c_int
+        L.oracle_lz4_compress_ex.argtypes = [c_char_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p,
+                                             POINTER(c_size_t)]
+        L.oracle_lz4_compress_ex.restype = c_int
         L.oracle_lz4_decompress.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t)]
         L.oracle_lz4_decompress.restype = c_int
         _lib = L
@@ -53,14 +60,17 @@ def lz4_hash_table_size(max_chunk: int) -> int:
 
 
 def lz4_compress(data: bytes, elem_size: int = 1, max_chunk_bytes: int | None = None,
-                 store_winner: int = STORE_WINNER_HIGHEST) -> bytes:
+                 store_winner: int = STORE_WINNER_GFX950, valid_offsets: bool = True) -> bytes:
+    """valid_offsets=True is the product's behaviour; False restates the
+    reference exactly (they differ only for typed chunks > 64 KiB, where the
+    reference emits truncated offsets)."""
     if max_chunk_bytes is None:
         max_chunk_bytes = len(data)
     cap = lz4_max_compressed_size(len(data)) + 16
     out = ctypes.create_string_buffer(cap)
     n = c_size_t(0)
-    rc = lib().oracle_lz4_compress(data, len(data), elem_size, max_chunk_bytes, store_winner,
-                                   ctypes.cast(out, c_void_p), ctypes.byref(n))
+    rc = lib().oracle_lz4_compress_ex(data, len(data), elem_size, max_chunk_bytes, store_winner,
+                                      1 if valid_offsets else 0, ctypes.cast(out, c_void_p), ctypes.byref(n))
     if rc != 0:
         raise ValueError("oracle_lz4_compress: bad arguments")
     return out.raw[: n.value]

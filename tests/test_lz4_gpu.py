@@ -48,21 +48,33 @@ def test_edge_chunks_bit_exact(hc, oracle, reflib, cuda, tname, dtype, es):
         assert codec.get_decompress_size(mine).cpu().tolist() == [len(c) for c in chunks]
 
 
-def test_large_u8_chunk_beyond_64k_elements(hc, oracle, reflib, cuda):
-    """> 65536 elements: exercises the 16-bit position wrap of the hash table."""
+def test_large_chunks_beyond_64k(hc, oracle, reflib, cuda):
+    """> 65536 elements: exercises the 16-bit position wrap of the hash table.
+    In typed modes the reference truncates byte offsets > 65535 (a corrupt
+    stream); the product rejects those candidates instead -- the one place
+    where bytes differ on purpose, and only for chunks > 64 KiB."""
     rng = np.random.default_rng(5)
     base = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))
     chunks = [(base * 100)[:250000], datagen.text_like(3, 200001), bytes(rng.integers(0, 3, 150000, dtype=np.uint8))]
     for dtype, es in ((0, 1), (4, 4)):
         src, mine, ref = _compress_both(hc, reflib, chunks, dtype, 250000)
         got = mine.to_host_chunks()
+        refgot = ref.to_host_chunks() if ref is not None else None
         for i, c in enumerate(chunks):
-            want = oracle.lz4_compress(c, es, 250000)
-            assert got[i] == want
-            if ref is not None:
-                assert ref.to_host_chunks()[i] == want
-        dec, actual, statuses = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype)).decompress(mine, 250016)
+            assert got[i] == oracle.lz4_compress(c, es, 250000, valid_offsets=True)
+            faithful = oracle.lz4_compress(c, es, 250000, valid_offsets=False)
+            if refgot is not None:
+                assert refgot[i] == faithful, "oracle (reference-faithful) != reference build"
+            if es == 1:
+                assert got[i] == faithful
+        codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
+        dec, actual, statuses = codec.decompress(mine, 250016)
+        assert statuses.cpu().tolist() == [0, 0, 0]
         assert dec.to_host_chunks() == chunks
+    # the reference's own typed stream of the text chunk does not decode to the input
+    bad = oracle.lz4_compress(chunks[1], 4, 250000, valid_offsets=False)
+    st, out = oracle.lz4_decompress(bad, 250016)
+    assert out != chunks[1]
 
 
 def test_reference_harness_batches(hc, oracle, reflib, cuda):

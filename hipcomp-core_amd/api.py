@@ -17,6 +17,14 @@ import ctypes
 import os
 from ctypes import POINTER, c_int, c_size_t, c_void_p
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be in
+# the process before libhipcomp.so is loaded so that the library binds to that
+# same runtime; otherwise the loader pulls a second copy from /opt/rocm and the
+# two runtimes do not share devices or allocations (hipPointerGetAttributes on
+# a torch tensor then fails with "no ROCm-capable device").  A C/C++ caller has
+# exactly one runtime and needs none of this.
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "lib", "libhipcomp.so")
 

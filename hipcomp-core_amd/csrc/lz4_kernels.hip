@@ -8,9 +8,10 @@
 //   --------------------------------------  ---------------------------------
 //   32 KiB hash table per chunk in HBM      table in LDS (ds_read_u16 /
 //   (temp space), global_store_short        ds_write_b16); temp space unused
-//   warpMatchAny = 64-step LDS loop, twice  in-window duplicate search by one
-//   per window (:218-245)                   ds_min_u32 on a small LDS slot
-//                                           table + one ds_bpermute, exact
+//   warpMatchAny = 64-step LDS loop, twice  in-window duplicate search through
+//   per window (:218-245)                   the hash table itself: lane ids
+//                                           posted in reversed lane order, one
+//                                           read-back + one ds_bpermute, exact
 //                                           fallback only for colliding lanes
 //   second warpMatchAny for the insert      insert rule (incl. the wave64
 //   (:722-741) + hardware arbitration of    `int` truncation)
@@ -34,8 +35,6 @@ namespace hcamd {
 namespace {
 
 constexpr uint32_t kNullOffset = 0xFFFFu;
-constexpr uint32_t kDupSlots = 1024; // ds_min slot table for in-window dups
-constexpr uint32_t kDupEmpty = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t hash_sum(uint32_t key)
 {
@@ -177,7 +176,7 @@ __device__ __forceinline__ uint32_t match_length(
     } else {
       diff_at = 0; // past the limit
     }
-    const uint64_t m = __ballot(diff_at < 4);
+    const uint64_t m = wave_ballot(diff_at < 4);
     if (m) {
       const int l = __builtin_ctzll(m);
       const uint32_t byte_idx = j + 4u * (uint32_t)l + read_lane(diff_at, l);
@@ -196,14 +195,15 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
     size_t* __restrict__ out_bytes,
     const uint32_t ht_size)
 {
+  // LDS holds the hash table and nothing else: 16384 x u16 = 32 KiB per
+  // chunk, so five chunks are resident per CU (5 x 32 KiB = the CU's 160 KiB).
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // LDS: [dup slot table: kDupSlots x u32][hash table: ht_size x u16]
-  uint32_t* dup_slots = reinterpret_cast<uint32_t*>(smem);
-  uint16_t* table = reinterpret_cast<uint16_t*>(smem + kDupSlots * 4);
+  uint16_t* table = reinterpret_cast<uint16_t*>(smem);
 
   constexpr uint32_t LVM = (12 + S - 1) / S; // last valid match, elements
   constexpr uint32_t MEL = (5 + S - 1) / S;  // min ending literals, elements
   constexpr int INV = 3 / S;                 // lanes without a full 4-byte word
+  constexpr int NVMAX = kWave - INV;
 
   const int lane = (int)threadIdx.x;
   const size_t chunk = blockIdx.x;
@@ -213,18 +213,24 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
   const uint32_t L = (len + S - 1) / S;
   const uint32_t hmask = ht_size - 1;
   const InsertPerm perm = make_insert_perm(lane);
+  const uint32_t rev_lane = 63u - (uint32_t)lane;
+  const int rev_addr4 = (int)(rev_lane * 4u);
 
   // ---- LDS init (reference :815-818 fills the table with NULL_OFFSET)
   {
     u32x4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     u32x4* p = reinterpret_cast<u32x4*>(smem);
-    const uint32_t nvec = (kDupSlots * 4 + ((ht_size * 2 + 15) & ~15u)) >> 4;
+    const uint32_t nvec = ((ht_size * 2 + 15) & ~15u) >> 4;
     for (uint32_t i = (uint32_t)lane; i < nvec; i += kWave)
       p[i] = ones;
   }
-  __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0); single wave: no barrier
 
   uint32_t d = 0, c = 0;
+  // `next` of the window at d when have_next (prefetched by the previous,
+  // match-less iteration)
+  uint32_t next = 0;
+  bool have_next = false;
+
   while (d < L) {
     const uint32_t token_start = d;
     for (;;) {
@@ -235,57 +241,70 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
         d = L;
         break;
       }
-      int nv = kWave - INV;
+      int nv = NVMAX;
       if ((int)(L - d - LVM) < nv)
         nv = (int)(L - d - LVM);
       const bool valid = lane < nv;
 
       // window word of lane t = the 4 bytes at element d+t (reference
       // :848-854; for every lane < nv none of them is masked)
-      uint32_t next = 0;
-      if (valid)
-        next = load_u32_any(in + (size_t)(d + (uint32_t)lane) * S);
-      const uint32_t hs = hash_sum(next);
-      const uint32_t hpos = hs & hmask;
+      // (loads are unconditional with a clamped, always readable index so
+      // that the compiler can count them: a load under a branch would force
+      // s_waitcnt vmcnt(0) at the first use of ANY older load)
+      const uint32_t last_word = L - LVM - 1; // highest element with 4 readable bytes
+      if (!have_next)
+        next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+      const uint32_t hpos = hash_sum(next) & hmask;
+      const uint32_t pos = d + (uint32_t)lane;
 
-      // (B) candidate from earlier windows: table lookup + 4-byte verify
-      // (reference isValidHash :634-663, convertIdx :619-632)
-      uint32_t cand = 0;
-      bool table_hit = false;
-      if (valid) {
-        const uint32_t h = table[hpos];
-        if (h != kNullOffset) {
-          const uint32_t pos = d + (uint32_t)lane;
-          cand = (pos & ~0xFFFFu) + h;
-          if (cand >= pos)
-            cand -= 65536u;
-          // The reference accepts any candidate within 65535 ELEMENTS and
-          // then truncates the byte offset to 16 bits (:651, :954), which
-          // corrupts typed-mode (S > 1) streams of chunks larger than 64 KiB.
-          // Candidates whose byte distance does not fit are rejected here;
-          // for chunks <= 64 KiB this never triggers, so those stay
-          // bit-identical (DESIGN.md "deliberate deviations").
-          const uint32_t dist = pos - cand;
-          if (dist <= 65535u && dist * S <= 65535u)
-            table_hit = load_u32_any(in + (size_t)cand * S) == next;
-        }
+      // (B) candidate from earlier windows (reference isValidHash :634-663,
+      // convertIdx :619-632): table read now, 4-byte verify load issued as
+      // early as possible.
+      const uint32_t h_old = valid ? (uint32_t)table[hpos] : kNullOffset;
+      uint32_t cand = (pos & ~0xFFFFu) + h_old;
+      if (cand >= pos)
+        cand -= 65536u;
+      const uint32_t dist = pos - cand;
+      // The reference accepts any candidate within 65535 ELEMENTS and then
+      // truncates the byte offset to 16 bits (:651, :954), which corrupts
+      // typed-mode (S > 1) streams of chunks larger than 64 KiB.  Candidates
+      // whose byte distance does not fit are rejected here; for chunks
+      // <= 64 KiB this never triggers, so those stay bit-identical
+      // (DESIGN.md "deliberate deviations").
+      const bool probe = h_old != kNullOffset && dist * S <= 65535u && dist <= 65535u;
+      const uint32_t cand_word
+          = load_u32_any(in + (size_t)(probe ? cand : min(pos, last_word)) * S);
+
+      // Speculative load of the next window (d + nv): issued AFTER the verify
+      // load so that waiting for the verify (in-order vmcnt) does not wait
+      // for it.  Used only if this window ends without a match.
+      const uint32_t next_pf = load_u32_any(
+          in + (size_t)min(d + (uint32_t)nv + (uint32_t)lane, last_word) * S);
+
+      // (A) in-window duplicates: lowest lane holding my word, found through
+      // the hash table itself (no scratch LDS).  Every valid lane posts its
+      // lane id into its own table slot with the lanes in REVERSED order, so
+      // that ds_write_b16's "highest lane wins" leaves the LOWEST window
+      // lane of each slot; reading the slot back names that lane.  If it
+      // holds my word it is exactly min{u : next_u == next_t}; otherwise two
+      // different words share the slot and the lane is settled by the exact
+      // fallback below.  The slots are then put back (h_old) before the real
+      // insert.
+      {
+        const uint32_t packed = hpos | (valid ? 0x80000000u : 0u);
+        const uint32_t pr = (uint32_t)__builtin_amdgcn_ds_bpermute(rev_addr4, (int)packed);
+        if (pr & 0x80000000u)
+          table[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
       }
-
-      // (A) in-window duplicates: lowest lane holding my word.  Every lane
-      // posts its id with ds_min into a slot chosen by its word; the slot
-      // then names the lowest lane of that slot.  If that lane holds my
-      // word it is exactly min{u : next_u == next_t}; otherwise (two words
-      // share a slot) the lane is "unresolved" and settled below.
-      const uint32_t slot = (hs >> 5) & (kDupSlots - 1);
+      const uint32_t w = valid ? (uint32_t)table[hpos] : (uint32_t)lane;
       if (valid)
-        atomicMin(&dup_slots[slot], (uint32_t)lane);
-      uint32_t w = valid ? dup_slots[slot] : (uint32_t)lane;
-      if (valid)
-        dup_slots[slot] = kDupEmpty;
-      const uint32_t nw = (uint32_t)__shfl((int)next, (int)w);
-      const bool eq = valid && (nw == next);
-      const uint64_t dupmask = __ballot(eq && w != (uint32_t)lane);
-      const uint64_t unres = __ballot(valid && !eq);
+        table[hpos] = (uint16_t)h_old;
+      const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)next);
+      // masks are combined as scalars: each ballot is one v_cmp
+      const uint64_t vmask = low_lanes_mask(nv);
+      const uint64_t eqmask = wave_ballot(nw == next) & vmask;
+      const uint64_t dupmask = eqmask & wave_ballot(w != (uint32_t)lane);
+      const uint64_t unres = vmask & ~eqmask;
 
       int f = nv;         // first lane with an equal lower lane
       uint32_t mlane = 0; // that lower lane
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
         const int u = __builtin_ctzll(U);
         U &= U - 1;
         const uint32_t v = read_lane(next, u);
-        const uint64_t m = __ballot(valid && next == v);
+        const uint64_t m = wave_ballot(next == v) & vmask;
         const int lo = __builtin_ctzll(m);
         if (lo != u) {
           f = u;
@@ -310,7 +329,8 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
 
       // earliest lane (< f) with a verified table candidate wins
       // (reference :896-923)
-      const uint64_t tmask = __ballot(table_hit && lane < f);
+      const uint64_t tmask
+          = wave_ballot(cand_word == next) & wave_ballot(probe) & low_lanes_mask(f);
       if (tmask) {
         f = __builtin_ctzll(tmask);
         match_location = read_lane(cand, f);
@@ -319,19 +339,22 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
       if (match_location != L) {
         // reference :925-956
         insert_window(table, hpos, d, f, lane, perm);
-        const uint32_t pos = d + (uint32_t)f;
-        const uint32_t off_elems = (pos - match_location) & 0xFFFFu;
-        const uint32_t lit = pos - token_start;
+        const uint32_t mpos = d + (uint32_t)f;
+        const uint32_t off_elems = (mpos - match_location) & 0xFFFFu;
+        const uint32_t lit = mpos - token_start;
         const uint32_t ml
-            = match_length<S>(in, match_location, pos, L - pos - MEL, lane);
+            = match_length<S>(in, match_location, mpos, L - mpos - MEL, lane);
         c = write_sequence(out, c, in + (size_t)token_start * S, lit * S,
                            ml * S, (off_elems * S) & 0xFFFFu, lane);
         d = token_start + lit + ml;
+        have_next = false;
         break;
       }
       // no match in this window (reference :958-962)
       insert_window(table, hpos, d, nv, lane, perm);
       d += (uint32_t)nv;
+      next = next_pf;
+      have_next = true;
     }
   }
   if (lane == 0)
@@ -446,7 +469,7 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
 
 size_t lz4_compress_lds_bytes(uint32_t ht_size)
 {
-  return kDupSlots * 4 + ((ht_size * 2 + 15) & ~15u);
+  return (ht_size * 2 + 15) & ~15u;
 }
 
 void lz4_launch_compress(

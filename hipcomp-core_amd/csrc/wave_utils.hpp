@@ -48,6 +48,13 @@ __device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane)
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
+// 64-bit ballot straight from the condition (HIP's __ballot goes through a
+// VGPR 0/1 value and a second compare).
+__device__ __forceinline__ uint64_t wave_ballot(bool p)
+{
+  return __builtin_amdgcn_ballot_w64(p);
+}
+
 __device__ __forceinline__ uint64_t low_lanes_mask(int n) // lanes [0, n)
 {
   return n >= 64 ? ~0ull : ((1ull << n) - 1ull);

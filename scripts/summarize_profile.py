@@ -5,7 +5,7 @@ rows = []
 for f in glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True):
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            name = re.sub(r"\(.*", "", r["Name"])[:90]
+            name = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", ""))[:90]
             rows.append((name, int(r["Calls"]), int(r["TotalDurationNs"]), float(r["AverageNs"]), float(r["Percentage"]),
                          int(r["MinNs"]), int(r["MaxNs"])))
 rows.sort(key=lambda x: -x[2])

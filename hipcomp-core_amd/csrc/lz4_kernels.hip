@@ -293,12 +293,16 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
       {
         const uint32_t packed = hpos | (valid ? 0x80000000u : 0u);
         const uint32_t pr = (uint32_t)__builtin_amdgcn_ds_bpermute(rev_addr4, (int)packed);
+        // (volatile: these values travel between lanes through LDS; the
+        // compiler must neither forward nor reorder them)
+        volatile uint16_t* vtable = table;
         if (pr & 0x80000000u)
-          table[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
+          vtable[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
       }
-      const uint32_t w = valid ? (uint32_t)table[hpos] : (uint32_t)lane;
+      volatile uint16_t* vtable = table;
+      const uint32_t w = valid ? (uint32_t)vtable[hpos] : (uint32_t)lane;
       if (valid)
-        table[hpos] = (uint16_t)h_old;
+        vtable[hpos] = (uint16_t)h_old;
       const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)next);
       // masks are combined as scalars: each ballot is one v_cmp
       const uint64_t vmask = low_lanes_mask(nv);

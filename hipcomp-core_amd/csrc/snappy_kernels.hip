@@ -1,0 +1,403 @@
+// snappy_kernels.hip -- gfx950 kernels of the batched raw-Snappy codec.
+//
+// Encoder: compressed bytes are those of the reference's wave64 encoder
+// (reference src/snappy/compression.hiph:190-385), by a different mechanism:
+//
+//   reference                                 here
+//   ----------------------------------------  -------------------------------
+//   128-thread block per chunk: wave 1        one wave per chunk does both
+//   searches, wave 0 emits the previous       (the two were strictly
+//   result, two __syncthreads per step        alternating anyway); 8 KiB LDS
+//                                             per chunk -> 20 chunks per CU
+//   HashMatchAny: 12 ballots + per-lane       lanes post their id into their
+//   64-bit xor/or per window (:157-172)       own hash-map slot (slot == hash,
+//                                             so no false sharing), read back
+//                                             the highest lane of the slot;
+//                                             only slots with >= 2 lanes get
+//                                             an exact ballot mask
+//   unaligned_load32: two aligned loads +     one unaligned global_load_dword
+//   funnel shift
+//   byte-per-lane literal copy                16-byte/lane copies
+//
+// The hash-map update mask `(2ULL << literal_cnt) - 1` with literal_cnt == 64
+// is a shift by the type width in the reference (:240); on gfx9 it evaluates
+// to 1 (v_lshlrev_b64 uses shift & 63), i.e. only lane 0 updates the map for a
+// window without a match.  Reproduced explicitly.
+//
+// Decoder: the Snappy format as the reference decodes it (reference
+// src/snappy/decompression.hiph:106-211, decompression_decode.hiph:72-150),
+// one wave per chunk; see DESIGN.md for the three places where undefined
+// behaviour of the reference is replaced by an error status.
+
+#include "snappy_launch.hpp"
+#include "wave_utils.hpp"
+
+namespace hcamd {
+
+namespace {
+
+constexpr uint32_t kHashBits = 12;
+constexpr uint32_t kHashEntries = 1u << kHashBits;
+constexpr uint32_t kMaxLiteral = 256;
+constexpr uint32_t kMaxCopyDistance = 32768;
+
+__device__ __forceinline__ uint32_t snap_hash(uint32_t v)
+{
+  return (v * ((1u << 20) + 0x2a00u + 0x6au + 1u)) >> (32 - kHashBits);
+}
+
+__global__ __launch_bounds__(kWave) void snappy_compress_kernel(
+    const uint8_t* const* __restrict__ in_ptrs,
+    const size_t* __restrict__ in_bytes,
+    uint8_t* const* __restrict__ out_ptrs,
+    size_t* __restrict__ out_bytes)
+{
+  __shared__ __attribute__((aligned(16))) uint16_t hash_map[kHashEntries];
+
+  const int lane = (int)threadIdx.x;
+  const size_t chunk = blockIdx.x;
+  cgptr __restrict__ src = to_global(in_ptrs[chunk]);
+  const uint32_t len = (uint32_t)in_bytes[chunk];
+  gptr __restrict__ dst = to_global(out_ptrs[chunk]);
+
+  // varint of the uncompressed length (reference :316-322)
+  uint32_t c = 0;
+  {
+    uint32_t v = len;
+    while (v > 0x7f) {
+      if (lane == 0)
+        dst[c] = (uint8_t)(v | 0x80);
+      ++c;
+      v >>= 7;
+    }
+    if (lane == 0)
+      dst[c] = (uint8_t)v;
+    ++c;
+  }
+  // hash map = 0 (reference :330-334)
+  {
+    u32x4 z = {0, 0, 0, 0};
+    u32x4* p = reinterpret_cast<u32x4*>(hash_map);
+    for (uint32_t i = (uint32_t)lane; i < kHashEntries * 2 / 16; i += kWave)
+      p[i] = z;
+  }
+
+  const uint64_t lane_bit = 1ull << lane;
+  const uint64_t below_me = lane_bit - 1;
+  const uint32_t last_word = len >= 4 ? len - 4 : 0; // highest readable dword start
+
+  uint32_t pos = 0;
+  if (len < 4) {
+    // no 4-byte word exists: the reference's search finds nothing and the
+    // chunk leaves as one literal (and no lane may load a dword from it)
+    if (len > 0) {
+      if (lane == 0)
+        dst[c] = (uint8_t)((len - 1) << 2);
+      if ((uint32_t)lane < len)
+        dst[c + 1 + lane] = src[lane];
+      c += 1 + len;
+    }
+    pos = len;
+  }
+  while (pos < len) {
+    // ---- FindFourByteMatch (reference :190-246)
+    const uint32_t pos0 = pos;
+    const uint32_t maxpos = pos0 + kMaxLiteral - (kWave - 1);
+    uint32_t p = pos0;
+    uint32_t copy_len = 0, distance = 0;
+    uint32_t literal_cnt;
+    do {
+      const uint32_t my = p + (uint32_t)lane;
+      const bool valid4 = my + 4 <= len;
+      const uint32_t raw = load_u32_any(src + min(my, last_word));
+      const uint32_t data32 = valid4 ? raw : 0;
+      const uint32_t hash = valid4 ? snap_hash(data32) : 0;
+
+      // table candidate first (its verify load is the long latency)
+      const uint32_t h_old = hash_map[hash];
+      uint32_t toff = (p & ~0xffffu) | h_old;
+      if (toff >= p)
+        toff = (toff >= 0x10000u) ? toff - 0x10000u : p;
+      const bool tprobe = valid4 && toff < p && toff + kMaxCopyDistance >= my;
+      const uint32_t tword = load_u32_any(src + (tprobe ? toff : min(my, last_word)));
+
+      // HashMatchAny (reference :157-172): all 64 lanes take part, lanes past
+      // the end with hash 0.  Post lane ids (highest lane survives), read the
+      // slot back, restore it.
+      // (volatile: the values travel between lanes through LDS, which the
+      // compiler must not forward from this lane's own store)
+      volatile uint16_t* vmap = hash_map;
+      vmap[hash] = (uint16_t)lane;
+      const uint32_t top = vmap[hash];
+      vmap[hash] = (uint16_t)h_old;
+      uint64_t local_match = lane_bit;
+      uint64_t pending = wave_ballot(top != (uint32_t)lane); // lanes in slots with >= 2 lanes
+      while (pending) {
+        const int u = __builtin_ctzll(pending);
+        const uint32_t hu = read_lane(hash, u);
+        const uint64_t gm = wave_ballot(hash == hu);
+        if (hash == hu)
+          local_match = gm;
+        pending &= ~gm;
+      }
+      if (!valid4)
+        local_match = 0;
+
+      // nearest lower lane with my hash
+      const uint64_t below = local_match & below_me;
+      const uint32_t lml = below ? (uint32_t)(63 - __builtin_clzll(below)) : 0xFFFFFFFFu;
+      const uint32_t lmd = (uint32_t)__builtin_amdgcn_ds_bpermute(
+          (int)(min(lml, (uint32_t)lane) * 4u), (int)data32);
+      const bool local_hit = valid4 && lml < (uint32_t)lane && lmd == data32;
+      const bool table_hit = !local_hit && tprobe && tword == data32;
+      const uint32_t offset = local_hit ? p + lml : toff;
+
+      const uint64_t match_mask = wave_ballot(local_hit || table_hit);
+      if (match_mask) {
+        literal_cnt = (uint32_t)__builtin_ctzll(match_mask);
+        distance = read_lane(my - offset, (int)literal_cnt);
+        copy_len = 4;
+      } else {
+        literal_cnt = kWave;
+      }
+      // hash-map update (reference :240-242); literal_cnt == 64 -> mask 1
+      const uint64_t upd = (2ull << (literal_cnt & 63u)) - 1ull;
+      const uint64_t m = local_match & upd;
+      if ((uint32_t)lane <= literal_cnt && m != 0 && lane == 63 - __builtin_clzll(m))
+        hash_map[hash] = (uint16_t)my;
+      p += literal_cnt;
+    } while (literal_cnt == kWave && p < maxpos);
+    const uint32_t lit = min(p, len) - pos0;
+
+    // ---- Match60 (reference :251-269)
+    if (copy_len) {
+      const uint32_t match_pos = pos0 + lit + 4;
+      const uint32_t n = min(len - match_pos, 60u);
+      bool mis = true;
+      if ((uint32_t)lane < n)
+        mis = src[match_pos + lane] != src[match_pos - distance + lane];
+      copy_len += (uint32_t)__builtin_ctzll(wave_ballot(mis));
+    }
+
+    // ---- StoreLiterals / StoreCopy (reference :73-151).  The output buffer
+    // holds 32 + n + n/6 bytes by contract, which this encoder cannot exceed
+    // (DESIGN.md), so the reference's per-byte bounds checks are not needed.
+    if (lit > 0) {
+      const uint32_t lm1 = lit - 1;
+      if (lm1 < 60) {
+        if (lane == 0)
+          dst[c] = (uint8_t)(lm1 << 2);
+        c += 1;
+      } else { // lit <= 256 -> one length byte
+        if (lane == 0) {
+          dst[c] = (uint8_t)(60 << 2);
+          dst[c + 1] = (uint8_t)lm1;
+        }
+        c += 2;
+      }
+      wave_copy(dst + c, src + pos0, lit, lane);
+      c += lit;
+    }
+    if (copy_len > 0) {
+      if (copy_len < 12 && distance < 2048) {
+        if (lane == 0) {
+          dst[c] = (uint8_t)(((distance & 0x700u) >> 3) | ((copy_len - 4) << 2) | 0x01u);
+          dst[c + 1] = (uint8_t)distance;
+        }
+        c += 2;
+      } else {
+        if (lane == 0) {
+          dst[c] = (uint8_t)(((copy_len - 1) << 2) | 0x2u);
+          dst[c + 1] = (uint8_t)distance;
+          dst[c + 2] = (uint8_t)(distance >> 8);
+        }
+        c += 3;
+      }
+    }
+    pos = pos0 + lit + copy_len;
+  }
+  if (lane == 0)
+    out_bytes[chunk] = c;
+}
+
+// Varint preamble (reference get_uncompressed_sizes_kernel,
+// SnappyBatchKernels.hip:84-134, and decode_uncompressed_size,
+// decompression.hiph:70-104).  Returns false on the ">= 2^31" error.
+__device__ __forceinline__ bool read_preamble(
+    cgptr comp, uint32_t end, uint32_t& cur, uint32_t& n)
+{
+  n = comp[cur++];
+  if (n > 0x7f) {
+    uint32_t c = (cur < end) ? comp[cur++] : 0;
+    n = (n & 0x7f) | (c << 7);
+    if (n >= (0x80u << 7)) {
+      c = (cur < end) ? comp[cur++] : 0;
+      n = (n & 0x3fff) | (c << 14);
+      if (n >= (0x80u << 14)) {
+        c = (cur < end) ? comp[cur++] : 0;
+        n = (n & 0x1fffff) | (c << 21);
+        if (n >= (0x80u << 21)) {
+          c = (cur < end) ? comp[cur++] : 0;
+          if (c < 0x8)
+            n = (n & 0xfffffff) | (c << 28);
+          else
+            return false;
+        }
+      }
+    }
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void snappy_get_sizes_kernel(
+    const uint8_t* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes, size_t* __restrict__ out_sizes,
+    size_t batch)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch)
+    return;
+  cgptr comp = to_global(comp_ptrs[i]);
+  const uint32_t end = (uint32_t)comp_bytes[i];
+  uint32_t n = 0;
+  if (end > 0) {
+    uint32_t cur = 0;
+    if (!read_preamble(comp, end, cur, n))
+      n = 0;
+  }
+  out_sizes[i] = n;
+}
+
+constexpr int kDecompWavesPerBlock = 4;
+
+__global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompress_kernel(
+    const uint8_t* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes,
+    const size_t* __restrict__ out_caps, const size_t batch,
+    uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
+    hipcompStatus_t* __restrict__ statuses)
+{
+  const int lane = lane_id();
+  const size_t chunk = (size_t)blockIdx.x * kDecompWavesPerBlock + (threadIdx.x >> 6);
+  if (chunk >= batch)
+    return;
+  cgptr comp = to_global(comp_ptrs[chunk]);
+  const uint32_t end = (uint32_t)comp_bytes[chunk];
+  gptr out = to_global(out_ptrs[chunk]);
+
+  uint32_t usize = 0, bytes_left = 0;
+  bool error = false;
+  if (end == 0) {
+    error = true;
+  } else {
+    uint32_t cur = 0;
+    if (!read_preamble(comp, end, cur, usize))
+      error = true;
+    size_t cap = out_caps[chunk];
+    if (cap == 0)
+      cap = usize; // reference decompression.hiph:148-149
+    if ((cur >= end && usize != 0) || usize > cap)
+      error = true;
+    if (error) {
+      usize = 0; // the reference reports size - bytes_left = 0 here
+    } else {
+      bytes_left = usize;
+      uint32_t dst_pos = 0;
+      while (bytes_left > 0) {
+        if (cur >= end)
+          break;
+        const uint32_t b0 = comp[cur];
+        uint32_t blen, offset;
+        if (b0 & 3u) {
+          if (!(b0 & 2u)) { // xxxxxx01.oooooooo
+            if (end - cur < 2)
+              break;
+            offset = ((b0 & 0xe0u) << 3) | comp[cur + 1];
+            blen = ((b0 >> 2) & 7u) + 4u;
+            cur += 2;
+          } else if (b0 & 1u) { // 4-byte offset
+            if (end - cur < 5)
+              break;
+            offset = load_u32_any(comp + cur + 1);
+            blen = (b0 >> 2) + 1u;
+            cur += 5;
+          } else { // 2-byte offset
+            if (end - cur < 3)
+              break;
+            offset = (uint32_t)comp[cur + 1] | ((uint32_t)comp[cur + 2] << 8);
+            blen = (b0 >> 2) + 1u;
+            cur += 3;
+          }
+          if (offset == 0 || offset > dst_pos || bytes_left < blen)
+            break;
+          // blen <= 64: one step, one byte per lane.  Earlier stores of this
+          // wave to out[] are ordered before these loads (one wave, in-order
+          // vector memory, one L1).
+          if ((uint32_t)lane < blen) {
+            const uint32_t k = offset >= blen ? (uint32_t)lane : (uint32_t)lane % offset;
+            out[dst_pos + lane] = out[dst_pos - offset + k];
+          }
+        } else {
+          blen = b0 >> 2;
+          cur += 1;
+          if (blen >= 60) {
+            const uint32_t nb = blen - 59;
+            if (end - cur < nb)
+              break;
+            blen = 0;
+            for (uint32_t i = 0; i < nb; ++i)
+              blen |= (uint32_t)comp[cur + i] << (8 * i);
+            cur += nb;
+          }
+          blen += 1;
+          if (blen == 0 || bytes_left < blen || end - cur < blen)
+            break;
+          wave_copy(out + dst_pos, comp + cur, blen, lane);
+          cur += blen;
+        }
+        dst_pos += blen;
+        bytes_left -= blen;
+      }
+      if (bytes_left != 0)
+        error = true;
+    }
+  }
+  if (lane == 0) {
+    if (actual_bytes)
+      actual_bytes[chunk] = usize - bytes_left; // reference decompression.hiph:197-198
+    if (statuses)
+      statuses[chunk] = error ? hipcompErrorCannotDecompress : hipcompSuccess;
+  }
+}
+
+} // namespace
+
+void snappy_launch_compress(
+    const uint8_t* const* in_ptrs, const size_t* in_bytes,
+    uint8_t* const* out_ptrs, size_t* out_bytes, size_t batch,
+    hipStream_t stream)
+{
+  snappy_compress_kernel<<<dim3((unsigned)batch), dim3(kWave), 0, stream>>>(
+      in_ptrs, in_bytes, out_ptrs, out_bytes);
+}
+
+void snappy_launch_decompress(
+    const uint8_t* const* comp_ptrs, const size_t* comp_bytes,
+    const size_t* out_caps, size_t batch, uint8_t* const* out_ptrs,
+    size_t* actual_bytes, hipcompStatus_t* statuses, hipStream_t stream)
+{
+  const unsigned grid = (unsigned)((batch + kDecompWavesPerBlock - 1) / kDecompWavesPerBlock);
+  snappy_decompress_kernel<<<dim3(grid), dim3(kWave * kDecompWavesPerBlock), 0, stream>>>(
+      comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
+}
+
+void snappy_launch_get_sizes(
+    const uint8_t* const* comp_ptrs, const size_t* comp_bytes,
+    size_t* out_sizes, size_t batch, hipStream_t stream)
+{
+  const unsigned grid = (unsigned)((batch + 255) / 256);
+  snappy_get_sizes_kernel<<<dim3(grid), dim3(256), 0, stream>>>(
+      comp_ptrs, comp_bytes, out_sizes, batch);
+}
+
+} // namespace hcamd

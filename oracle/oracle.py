@@ -45,6 +45,14 @@ def lib():
         L.oracle_lz4_compress_ex.restype = c_int
         L.oracle_lz4_decompress.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t)]
         L.oracle_lz4_decompress.restype = c_int
+        L.oracle_snappy_max_compressed_size.argtypes = [c_size_t]
+        L.oracle_snappy_max_compressed_size.restype = c_size_t
+        L.oracle_snappy_compress.argtypes = [c_char_p, c_size_t, c_void_p, POINTER(c_size_t)]
+        L.oracle_snappy_compress.restype = c_int
+        L.oracle_snappy_uncompressed_size.argtypes = [c_char_p, c_size_t]
+        L.oracle_snappy_uncompressed_size.restype = c_size_t
+        L.oracle_snappy_decompress.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t)]
+        L.oracle_snappy_decompress.restype = c_int
         _lib = L
     return _lib
 
@@ -89,3 +97,29 @@ def lz4_decompressed_size(comp: bytes):
     n = c_size_t(0)
     st = lib().oracle_lz4_decompress(comp, len(comp), None, 0, ctypes.byref(n))
     return st, n.value
+
+
+# ---- Snappy ----------------------------------------------------------------
+
+def snappy_max_compressed_size(n: int) -> int:
+    return lib().oracle_snappy_max_compressed_size(n)
+
+
+def snappy_compress(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(snappy_max_compressed_size(len(data)) + 16)
+    n = c_size_t(0)
+    lib().oracle_snappy_compress(data, len(data), ctypes.cast(out, c_void_p), ctypes.byref(n))
+    return out.raw[: n.value]
+
+
+def snappy_uncompressed_size(comp: bytes) -> int:
+    return lib().oracle_snappy_uncompressed_size(comp, len(comp))
+
+
+def snappy_decompress(comp: bytes, capacity: int):
+    """-> (status, bytes produced).  capacity 0 = the stream's own size."""
+    room = max(capacity, snappy_uncompressed_size(comp) if capacity == 0 else capacity, 1)
+    out = ctypes.create_string_buffer(room)
+    n = c_size_t(0)
+    st = lib().oracle_snappy_decompress(comp, len(comp), ctypes.cast(out, c_void_p), capacity, ctypes.byref(n))
+    return st, out.raw[: n.value]

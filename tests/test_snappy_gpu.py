@@ -1,0 +1,119 @@
+"""Snappy parity on the GPU through the C ABI: compressed bytes vs the CPU
+oracle and vs the reference build (oracle/_ref), round trips, the reference's
+golden decoder vectors and large-token cases, error paths."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+from test_snappy_oracle_cpu import copy_tag, literal_tag, varint
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _chunks():
+    named = datagen.edge_chunks()
+    named += [("lt4_%d" % n, bytes(range(n))) for n in (1, 2, 3, 4, 5)]
+    named += [("seq256", bytes(range(256))), ("seq256_copy64", bytes(range(256)) + bytes(range(64)))]
+    named += [("csv", datagen.text_like(77, 65536).replace(b" ", b"|"))]
+    return named
+
+
+def test_compress_bit_exact_and_roundtrip(hc, oracle, reflib, cuda):
+    import torch
+    named = _chunks()
+    chunks = [c for _, c in named]
+    src = hc.batch.from_host_chunks(chunks, "cuda:0")
+    codec = hc.batch.Codec("Snappy")
+    mine = codec.compress(src)
+    torch.cuda.synchronize()
+    got = mine.to_host_chunks()
+    refgot = None
+    if reflib is not None:
+        r = hc.batch.Codec("Snappy", lib=reflib).compress(src)
+        torch.cuda.synchronize()
+        refgot = r.to_host_chunks()
+    for i, (name, c) in enumerate(named):
+        want = oracle.snappy_compress(c)
+        assert got[i] == want, f"{name}: kernel != oracle"
+        if refgot is not None:
+            assert refgot[i] == want, f"{name}: oracle != reference build"
+    assert codec.get_decompress_size(mine).cpu().tolist() == [len(c) for c in chunks]
+    dec, actual, statuses = codec.decompress(mine, 65536)
+    assert statuses.cpu().tolist() == [0] * len(chunks)
+    assert actual.cpu().tolist() == [len(c) for c in chunks]
+    assert dec.to_host_chunks() == chunks
+    if reflib is not None:  # the reference decodes our streams too
+        rdec, ractual, rstat = hc.batch.Codec("Snappy", lib=reflib).decompress(mine, 65536)
+        assert rstat.cpu().tolist() == [0] * len(chunks)
+        assert rdec.to_host_chunks() == chunks
+
+
+def test_reference_harness_batches(hc, oracle, reflib, cuda):
+    import torch
+    for bi, chunks in enumerate(datagen.harness_batches()):
+        src = hc.batch.from_host_chunks(chunks, "cuda:0")
+        codec = hc.batch.Codec("Snappy")
+        mine = codec.compress(src)
+        torch.cuda.synchronize()
+        got = mine.to_host_chunks()
+        if reflib is not None:
+            r = hc.batch.Codec("Snappy", lib=reflib).compress(src)
+            torch.cuda.synchronize()
+            assert got == r.to_host_chunks(), f"batch {bi}: kernel != reference build"
+        step = max(1, len(chunks) // 64)
+        for i in range(0, len(chunks), step):
+            assert got[i] == oracle.snappy_compress(chunks[i])
+        assert codec.get_decompress_size(mine).cpu().tolist() == [len(c) for c in chunks]
+        dec, actual, statuses = codec.decompress(mine, max(len(c) for c in chunks))
+        assert statuses.cpu().tolist() == [0] * len(chunks)
+        assert dec.to_host_chunks() == chunks
+        dec2, _, _ = codec.decompress(mine, max(len(c) for c in chunks), with_status=False)
+        torch.cuda.synchronize()
+        dec2.sizes = src.sizes
+        assert dec2.to_host_chunks() == chunks
+
+
+def test_reference_decoder_vectors_and_large_tokens(hc, cuda):
+    with open(os.path.join(HERE, "golden", "snappy_app_vectors.json")) as f:
+        vecs = json.load(f)["vectors"]
+    streams = [bytes.fromhex(v["compressed_hex"]) for v in vecs]
+    expect = [bytes.fromhex(v["expected_hex"]) for v in vecs]
+    # tokens the GPU encoder never emits (SnappyLargeTokens_test.cpp:452-537)
+    data = bytes(i % 256 for i in range(512))
+    streams.append(varint(512) + literal_tag(512) + data)
+    expect.append(data)
+    rng = np.random.default_rng(42)
+    for n in ((1 << 15) + 100, (1 << 16) + 100):
+        vals = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        streams.append(varint(n + 35) + literal_tag(n) + vals + copy_tag(n, 35))
+        expect.append(vals + vals[:35])
+    comp = hc.batch.from_host_chunks(streams, "cuda:0")
+    codec = hc.batch.Codec("Snappy")
+    assert codec.get_decompress_size(comp).cpu().tolist() == [len(e) for e in expect]
+    dec, actual, statuses = codec.decompress(comp, max(len(e) for e in expect))
+    assert statuses.cpu().tolist() == [0] * len(streams)
+    assert dec.to_host_chunks() == expect
+
+
+def test_decoder_error_paths_match_oracle(hc, oracle, cuda):
+    data = datagen.text_like(4, 5000)
+    good = oracle.snappy_compress(data)
+    raw = datagen.harness_like_int32(3, 2000).tobytes()
+    streams = [good, good[:-5], good[:40], b"", varint(10) + copy_tag(5, 4), b"\xff\xff\xff\xff\x7f", b"\x00", raw,
+               varint(100) + literal_tag(50) + b"x" * 10]
+    for cap in (5000, 4999, 8000):
+        comp = hc.batch.from_host_chunks(streams, "cuda:0")
+        dec, actual, statuses = hc.batch.Codec("Snappy").decompress(comp, cap)
+        st, ac = statuses.cpu().tolist(), actual.cpu().tolist()
+        for i, s in enumerate(streams):
+            ost, obytes = oracle.snappy_decompress(s, cap)
+            assert st[i] == ost, (i, cap)
+            assert ac[i] == len(obytes), (i, cap)
+            if ost == 0:
+                assert dec.chunk_bytes(i, ac[i]) == obytes
+    sizes = hc.batch.Codec("Snappy").get_decompress_size(hc.batch.from_host_chunks(streams, "cuda:0")).cpu().tolist()
+    assert sizes == [oracle.snappy_uncompressed_size(s) for s in streams]

@@ -7,7 +7,7 @@ the reference's low-level sources compiled unmodified by oracle/Makefile):
 
 Inputs are regenerated from tests/datagen.py (seeded), so the fixture holds
 only the reference's OUTPUT: full compressed bytes for small chunks, SHA-256 +
-length for large ones.  The committed result is tests/golden/lz4_reference.json.
+length for large ones.  The committed results are tests/golden/{lz4,snappy}_reference.json.
 """
 import base64
 import hashlib
@@ -65,7 +65,19 @@ def main(outdir):
     os.makedirs(outdir, exist_ok=True)
     with open(os.path.join(outdir, "lz4_reference.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
-    print("wrote", len(out["lz4"]), "records")
+    print("wrote", len(out["lz4"]), "lz4 records")
+
+    # ---- Snappy (one configuration: the codec has no options)
+    sn = {"generator": out["generator"], "library": out["library"], "device": out["device"], "snappy": []}
+    comp = hc.batch.Codec("Snappy", lib=ref).compress(src)
+    torch.cuda.synchronize()
+    for (name, c), g in zip(named, comp.to_host_chunks()):
+        rec = record(g)
+        rec.update({"case": name, "in_len": len(c), "in_sha256": hashlib.sha256(c).hexdigest()})
+        sn["snappy"].append(rec)
+    with open(os.path.join(outdir, "snappy_reference.json"), "w") as f:
+        json.dump(sn, f, separators=(",", ":"))
+    print("wrote", len(sn["snappy"]), "snappy records")
 
 
 if __name__ == "__main__":

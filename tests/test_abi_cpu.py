@@ -73,3 +73,24 @@ def test_lz4_size_query_errors(hc):
     # 65536-byte chunks: the numbers SURVEY.md 8(a) L1/L2 quote
     assert lib.compress_temp_size("LZ4", 100000, 65536, opts) == 3276800000
     assert lib.max_output_chunk_size("LZ4", 65536, opts) == 65800
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 6, 65536, 1 << 24])
+def test_snappy_size_queries(hc, oracle, n):
+    lib = hc.default_library()
+    opts = hc.SnappyOpts(0)
+    assert lib.max_output_chunk_size("Snappy", n, opts) == 32 + n + n // 6 == oracle.snappy_max_compressed_size(n)
+    assert lib.compress_temp_size("Snappy", 1000, n, opts) == 0
+    assert lib.decompress_temp_size("Snappy", 1000, n) == 0
+    assert lib.max_output_chunk_size("Snappy", 65536, opts) == 76490 or n != 65536
+
+
+def test_snappy_null_arguments(hc):
+    lib = hc.default_library()
+    opts = hc.SnappyOpts(0)
+    assert lib.hipcompBatchedSnappyCompressGetTempSize(1, 1, opts, None) == 10
+    assert lib.hipcompBatchedSnappyCompressGetMaxOutputChunkSize(1, opts, None) == 10
+    assert lib.hipcompBatchedSnappyDecompressGetTempSize(1, 1, None) == 10
+    assert lib.hipcompBatchedSnappyCompressAsync(None, None, 0, 1, None, 0, None, None, opts, None) == 10
+    assert lib.hipcompBatchedSnappyDecompressAsync(None, None, None, None, 1, None, 0, None, None, None) == 10
+    assert lib.hipcompBatchedSnappyGetDecompressSizeAsync(None, None, None, 1, None) == 10

@@ -47,3 +47,17 @@ def test_lz4_oracle_reproduces_reference_output(oracle, golden, inputs):
         # the product's form is identical for chunks <= 64 KiB
         assert got == oracle.lz4_compress(data, r["elem_size"], r["max_chunk"], valid_offsets=True)
     assert full >= 100
+
+
+def test_snappy_oracle_reproduces_reference_output(oracle, inputs):
+    with open(os.path.join(HERE, "golden", "snappy_reference.json")) as f:
+        recs = json.load(f)["snappy"]
+    assert len(recs) >= 40
+    for r in recs:
+        data = inputs[r["case"]]
+        assert hashlib.sha256(data).hexdigest() == r["in_sha256"], r["case"]
+        got = oracle.snappy_compress(data)
+        assert len(got) == r["len"], r["case"]
+        assert hashlib.sha256(got).hexdigest() == r["sha256"], r["case"]
+        if "b64" in r:
+            assert got == base64.b64decode(r["b64"])

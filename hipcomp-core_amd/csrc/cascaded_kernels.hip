@@ -1,0 +1,682 @@
+// cascaded_kernels.hip -- gfx950 kernels of the batched Cascaded codec
+// (RLE -> Delta -> BitPack fused over 4096-byte sub-chunks, all in LDS).
+//
+// Wire format and layer semantics: reference src/CascadedKernels.hiph:101-1435
+// (restated in oracle/cascaded_oracle.c).  Mechanism:
+//
+//   reference                                 here
+//   ----------------------------------------  -------------------------------
+//   one 128-thread block per partition,       one WAVE per partition, four
+//   6+ __syncthreads per layer, hipCUB        partitions per 256-thread block:
+//   BlockScan / BlockReduce                   no block barrier at all; run
+//                                             ends ranked with one ballot +
+//                                             popcount per 64 elements, min /
+//                                             max by DPP-style shuffles
+//   RLE: count pass, scan, scatter pass,      one pass: value, rank and run
+//   adjacent-difference pass                  length from the same ballot
+//   bit-packed arrays built in LDS, then      packed words go straight from
+//   copied out word by word                   the LDS element array to HBM
+//   decompress: 4 launches, type taken from   4 launches (LDS sized per
+//   partition 0, RLE expand = 1 thread/run    width), type taken from EACH
+//                                             partition; RLE expand = binary
+//                                             search per output element
+//
+// Bytes the reference leaves undefined (stale LDS / unwritten gaps,
+// SURVEY.md App. C.4) are written as 0 here, so the output is deterministic.
+
+#include "cascaded_launch.hpp"
+#include "wave_utils.hpp"
+
+#include <type_traits>
+
+namespace hcamd {
+
+namespace {
+
+constexpr uint32_t kChunkBytes = 4096;
+constexpr uint32_t kPartMeta = 8;
+constexpr int kWavesPerBlock = 4;
+
+template <int S> struct UIntOf;
+template <> struct UIntOf<1> { typedef uint8_t type; typedef int8_t stype; };
+template <> struct UIntOf<2> { typedef uint16_t type; typedef int16_t stype; };
+template <> struct UIntOf<4> { typedef uint32_t type; typedef int32_t stype; };
+template <> struct UIntOf<8> { typedef uint64_t type; typedef int64_t stype; };
+
+__device__ __forceinline__ uint32_t ru(uint32_t a, uint32_t b) { return (a + b - 1) / b * b; }
+
+__host__ __device__ constexpr uint32_t elem_buf_bytes() { return kChunkBytes + 16; }
+
+template <int S>
+__host__ __device__ constexpr uint32_t wave_lds_bytes()
+{
+  // two element buffers + one run-count array + 64-byte chunk-metadata image
+  return 2 * elem_buf_bytes() + (kChunkBytes / S) * 2 + 64;
+}
+
+// ---- wave reductions (64 lanes) -------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_min(T v)
+{
+  for (int o = 32; o > 0; o >>= 1) {
+    T u = __shfl_xor(v, o);
+    v = u < v ? u : v;
+  }
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v)
+{
+  for (int o = 32; o > 0; o >>= 1) {
+    T u = __shfl_xor(v, o);
+    v = u > v ? u : v;
+  }
+  return v;
+}
+
+// ---- RLE of n elements: values, run lengths, number of runs ----------------
+// (reference block_rle_compress :124-241)
+template <typename UT>
+__device__ __forceinline__ uint32_t wave_rle(
+    const UT* in, uint32_t n, UT* vals, uint16_t* cnts, int lane)
+{
+  uint32_t m = 0, prev_end = 0;
+  const uint64_t below_me = (1ull << lane) - 1;
+  for (uint32_t base = 0; base < n; base += kWave) {
+    const uint32_t i = base + (uint32_t)lane;
+    const bool active = i < n;
+    const UT v = active ? in[i] : (UT)0;
+    const UT nx = (i + 1 < n) ? in[i + 1] : (UT)0;
+    const bool is_end = active && (i + 1 == n || nx != v);
+    const uint64_t mask = wave_ballot(is_end);
+    const uint64_t below = mask & below_me;
+    const uint32_t rank = m + (uint32_t)__builtin_popcountll(below);
+    const uint32_t pe = below ? base + 64u - (uint32_t)__builtin_clzll(below) : prev_end;
+    if (is_end) {
+      vals[rank] = v;
+      cnts[rank] = (uint16_t)(i + 1 - pe);
+    }
+    m += (uint32_t)__builtin_popcountll(mask);
+    if (mask)
+      prev_end = base + 64u - (uint32_t)__builtin_clzll(mask);
+  }
+  return m;
+}
+
+// ---- one array to HBM (reference block_write :646-680 / block_bitpack) ----
+// Returns the byte length the format records; words are written at
+// out + off (4-byte aligned).  `limit` is the partition's output limit in
+// bytes; returns 0xFFFFFFFF when the array does not fit (reference :668-671).
+template <typename ET>
+__device__ __forceinline__ uint32_t wave_write_array(
+    gptr out, uint32_t off, uint32_t limit, const ET* v, uint32_t n, int bp, int lane)
+{
+  typedef typename std::make_signed<ET>::type SET;
+  constexpr uint32_t ES = sizeof(ET);
+  HC_GLOBAL uint32_t* dst = reinterpret_cast<HC_GLOBAL uint32_t*>(out + off);
+  if (!bp) {
+    const uint32_t ob = n * ES;
+    const uint32_t words = (ob + 3) / 4;
+    if (off + words * 4 > limit)
+      return 0xFFFFFFFFu;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(v);
+    for (uint32_t w = (uint32_t)lane; w < words; w += kWave) {
+      uint32_t x = src[w];
+      const uint32_t valid_bytes = ob - 4 * w; // < 4 only in the last word
+      if (valid_bytes < 4)
+        x &= (1u << (8 * valid_bytes)) - 1u;
+      dst[w] = x;
+    }
+    return ob;
+  }
+  // frame of reference = minimum under the SIGNED interpretation, bit width
+  // from max - min (reference get_for_bitwidth :394-471)
+  SET mn = 0, mx = 0;
+  if (n > 0) {
+    mn = (SET)v[0];
+    mx = mn;
+    for (uint32_t i = (uint32_t)lane; i < n; i += kWave) {
+      const SET x = (SET)v[i];
+      mn = x < mn ? x : mn;
+      mx = x > mx ? x : mx;
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+  }
+  uint32_t bw;
+  if (ES > 4) {
+    const uint64_t range = (uint64_t)mx - (uint64_t)mn;
+    bw = range ? 64u - (uint32_t)__builtin_clzll(range) : 0u;
+  } else {
+    const uint32_t range = (uint32_t)(int32_t)mx - (uint32_t)(int32_t)mn;
+    bw = range ? 32u - (uint32_t)__builtin_clz(range) : 0u;
+  }
+  const uint32_t words = (n * bw + 31) / 32;
+  constexpr uint32_t HDR = ES > 4 ? 16 : 8; // roundUp(ES + 4, max(4, ES))
+  const uint32_t ob = HDR + 4 * words;
+  if (off + ob > limit)
+    return 0xFFFFFFFFu;
+  const ET fr = (ET)mn;
+  if (lane == 0) {
+    // [FOR][pad to 4][bitwidth<<16 | n][pad to ES]; pads written as 0
+    if (ES > 4) {
+      dst[0] = (uint32_t)((uint64_t)fr);
+      dst[1] = (uint32_t)((uint64_t)fr >> 32);
+      dst[2] = (bw << 16) | n;
+      dst[3] = 0;
+    } else {
+      dst[0] = (uint32_t)fr; // zero-extended: pad bytes are 0
+      dst[1] = (bw << 16) | n;
+    }
+  }
+  HC_GLOBAL uint32_t* data = dst + HDR / 4;
+  for (uint32_t w = (uint32_t)lane; w < words; w += kWave) {
+    // LSB-first packing of (x - FOR) in bw bits (reference :523-552)
+    const uint32_t b0 = w * 32;
+    uint32_t acc = 0;
+    for (uint32_t i = b0 / bw; i * bw < b0 + 32 && i < n; ++i) {
+      const ET x = (ET)(v[i] - fr);
+      const int sh = (int)(i * bw) - (int)b0;
+      if (ES > 4) {
+        const uint64_t xx = (uint64_t)x;
+        acc |= (uint32_t)(sh > 0 ? xx << sh : xx >> (-sh));
+      } else {
+        const uint32_t xx = (uint32_t)x;
+        acc |= sh > 0 ? xx << sh : xx >> (-sh);
+      }
+    }
+    data[w] = acc;
+  }
+  return ob;
+}
+
+template <int S>
+__device__ __forceinline__ uint32_t chunk_metadata_size(int R, int D)
+{
+  return ru((uint32_t)(4 + 4 * (R + 1)), (uint32_t)S) + ru((uint32_t)(S * D), 4u);
+}
+
+template <int S>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kernel(
+    const uint8_t* const* __restrict__ in_ptrs,
+    const size_t* __restrict__ in_bytes_arr,
+    uint8_t* const* __restrict__ out_ptrs,
+    size_t* __restrict__ out_bytes_arr, const size_t batch, const int type_tag,
+    const int R, const int D, const int bp)
+{
+  typedef typename UIntOf<S>::type UT;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * wave_lds_bytes<S>()];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const size_t part = (size_t)blockIdx.x * kWavesPerBlock + wave;
+  if (part >= batch)
+    return;
+  uint8_t* my = smem + wave * wave_lds_bytes<S>();
+  UT* bufA = reinterpret_cast<UT*>(my);
+  UT* bufB = reinterpret_cast<UT*>(my + elem_buf_bytes());
+  uint16_t* cnts = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes());
+  uint32_t* meta = reinterpret_cast<uint32_t*>(my + 2 * elem_buf_bytes() + (kChunkBytes / S) * 2);
+
+  cgptr in = to_global(in_ptrs[part]);
+  const size_t in_bytes64 = in_bytes_arr[part];
+  gptr out = to_global(out_ptrs[part]);
+  if (in == nullptr || in_bytes64 == 0) { // reference :856-860
+    if (lane == 0)
+      out_bytes_arr[part] = 0;
+    return;
+  }
+  const uint32_t in_bytes = (uint32_t)in_bytes64;
+  const uint32_t N = in_bytes / S;
+  const uint32_t limit = 4u * (2u + (in_bytes + 3u) / 4u); // reference :852-854
+  bool use = !(R == 0 && D == 0 && bp == 0);
+  uint32_t cur = ru(kPartMeta, S);
+  constexpr uint32_t CE = kChunkBytes / S;
+  const uint32_t nchunks = (N + CE - 1) / CE;
+  const uint32_t msz = chunk_metadata_size<S>(R, D);
+  const uint32_t dh_off = ru((uint32_t)(4 + 4 * (R + 1)), (uint32_t)S);
+  const int layers = R > D ? R : D;
+
+  for (uint32_t c = 0; c < nchunks && use; ++c) {
+    const uint32_t chunk_start = cur;
+    cur += msz;
+    uint32_t n = min(N - c * CE, CE);
+    // sub-chunk -> LDS (16 bytes per lane per step; inputs are 4-byte aligned)
+    {
+      cgptr src = in + (size_t)c * kChunkBytes;
+      const uint32_t nb = n * S;
+      uint32_t* dstw = reinterpret_cast<uint32_t*>(bufA);
+      for (uint32_t o = (uint32_t)lane * 16u; o < nb; o += kWave * 16u) {
+        if (o + 16 <= nb) {
+          const u32x4 q = load_u128_any(src + o);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(bufA) + o) = q;
+        } else {
+          for (uint32_t k = o; k < nb; ++k)
+            reinterpret_cast<uint8_t*>(bufA)[k] = src[k];
+        }
+      }
+      (void)dstw;
+      if (lane < 16)
+        meta[lane] = 0;
+    }
+    UT* x = bufA;
+    UT* y = bufB;
+    int rr = R, dr = D;
+    for (int l = 0; l < layers && use; ++l) {
+      if (rr > 0) { // reference :913-953
+        const uint32_t m = wave_rle<UT>(x, n, y, cnts, lane);
+        const uint32_t ob = wave_write_array<uint16_t>(out, cur, limit, cnts, m, bp, lane);
+        if (ob == 0xFFFFFFFFu) {
+          use = false;
+          break;
+        }
+        cur += ru(ob, 4);
+        if (lane == 0)
+          meta[R - rr + 1] = ob;
+        UT* t = x; x = y; y = t;
+        n = m;
+        --rr;
+      }
+      if (dr > 0) { // reference :955-977
+        if (n == 0) { // undefined in the reference (:323); raw fallback here
+          use = false;
+          break;
+        }
+        if (lane == 0)
+          *reinterpret_cast<UT*>(reinterpret_cast<uint8_t*>(meta) + dh_off + (D - dr) * S) = x[0];
+        for (uint32_t i = (uint32_t)lane; i + 1 < n; i += kWave)
+          y[i] = (UT)(x[i + 1] - x[i]);
+        UT* t = x; x = y; y = t;
+        n -= 1;
+        --dr;
+      }
+    }
+    if (!use)
+      break;
+    const uint32_t fin = ru(cur, S); // reference :983-984
+    if (S > 4 && fin > cur && lane == 0)
+      *reinterpret_cast<HC_GLOBAL uint32_t*>(out + cur) = 0; // alignment gap
+    const uint32_t ob = wave_write_array<UT>(out, fin, limit, x, n, bp, lane);
+    if (ob == 0xFFFFFFFFu) {
+      use = false;
+      break;
+    }
+    const uint32_t after = fin + ru(ob, 4);
+    cur = ru(after, S); // reference :999-1001
+    if (S > 4 && cur > after && lane == 0)
+      *reinterpret_cast<HC_GLOBAL uint32_t*>(out + after) = 0;
+    if (lane == 0) {
+      meta[0] = cur - chunk_start;
+      meta[R + 1] = ob;
+    }
+    // flush the chunk metadata image (reference :1004-1014)
+    if ((uint32_t)lane < msz / 4)
+      reinterpret_cast<HC_GLOBAL uint32_t*>(out + chunk_start)[lane] = meta[lane];
+  }
+
+  uint32_t total;
+  if (use) {
+    total = cur;
+  } else { // raw fallback (reference :1019-1053)
+    const uint32_t raw = ru(kPartMeta, S);
+    const uint32_t nb = N * S;
+    wave_copy(out + raw, in, nb, lane);
+    if ((nb & 3u) && lane == 0)
+      for (uint32_t k = nb; k < ru(nb, 4); ++k)
+        out[raw + k] = 0;
+    total = raw + ru(nb, 4);
+  }
+  if (lane == 0) {
+    const uint32_t h = use ? ((uint32_t)R | ((uint32_t)D << 8) | ((uint32_t)bp << 16)) : 0u;
+    reinterpret_cast<HC_GLOBAL uint32_t*>(out)[0] = h | ((uint32_t)type_tag << 24);
+    reinterpret_cast<HC_GLOBAL uint32_t*>(out)[1] = N * S;
+    out_bytes_arr[part] = total;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Decoder
+// ---------------------------------------------------------------------------
+
+// One array from HBM into LDS (reference block_read :702-737 +
+// block_bitunpack :563-618).  Returns the element count, or -1 when the array
+// leaves the partition / the sub-chunk.
+template <typename ET>
+__device__ __forceinline__ int wave_read_array(
+    cgptr comp, uint32_t end_words, uint32_t off, uint32_t nbytes, int bp,
+    ET* dst, uint32_t max_elems, int lane)
+{
+  constexpr uint32_t ES = sizeof(ET);
+  if ((off & 3u) || (off + ru(nbytes, 4)) / 4 > end_words)
+    return -1;
+  if (!bp) {
+    const uint32_t n = nbytes / ES;
+    if (n > max_elems)
+      return -1;
+    const uint32_t words = (n * ES + 3) / 4;
+    const HC_GLOBAL uint32_t* src = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    for (uint32_t w = (uint32_t)lane; w < words; w += kWave)
+      d[w] = src[w];
+    return (int)n;
+  }
+  constexpr uint32_t HDR = ES > 4 ? 16 : 8;
+  constexpr uint32_t WOFF = ES > 4 ? 8 : 4;
+  if (nbytes < HDR)
+    return -1;
+  ET fr;
+  if (ES > 4)
+    fr = (ET)((uint64_t)*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off)
+              | ((uint64_t)*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off + 4) << 32));
+  else
+    fr = (ET)*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off);
+  const uint32_t word = *reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off + WOFF);
+  const uint32_t bw = word >> 16;
+  const uint32_t n = word & 0xFFFFu;
+  if (n == 0)
+    return 0;
+  if (n > max_elems || bw > 8 * ES)
+    return -1;
+  const uint32_t words = (n * bw + 31) / 32;
+  if (HDR + 4 * words > ru(nbytes, 4))
+    return -1;
+  const HC_GLOBAL uint32_t* data = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off + HDR);
+  for (uint32_t i = (uint32_t)lane; i < n; i += kWave) {
+    ET x = 0;
+    if (bw) {
+      const uint32_t bit = i * bw;
+      const uint32_t w0 = bit >> 5, sh = bit & 31u;
+      const uint32_t last = words - 1;
+      const uint64_t lo = (uint64_t)data[w0] | ((uint64_t)data[min(w0 + 1, last)] << 32);
+      uint64_t v = lo >> sh;
+      if (ES > 4 && sh + bw > 64)
+        v |= (uint64_t)data[min(w0 + 2, last)] << (64 - sh);
+      const uint64_t m = bw >= 64 ? ~0ull : ((1ull << bw) - 1ull);
+      x = (ET)(v & m);
+    }
+    dst[i] = (ET)(x + fr);
+  }
+  return (int)n;
+}
+
+template <int S>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_decompress_kernel(
+    const uint8_t* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes_arr,
+    const size_t* __restrict__ out_caps, const size_t batch,
+    uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
+    hipcompStatus_t* __restrict__ statuses)
+{
+  typedef typename UIntOf<S>::type UT;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * wave_lds_bytes<S>()];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const size_t part = (size_t)blockIdx.x * kWavesPerBlock + wave;
+  if (part >= batch)
+    return;
+  cgptr comp = to_global(comp_ptrs[part]);
+  const size_t comp_bytes64 = comp_bytes_arr[part];
+  const bool bad_header = comp == nullptr || comp_bytes64 < kPartMeta;
+  uint32_t type = 0xFFu;
+  if (!bad_header)
+    type = comp[3];
+  // Each width has its own launch; a partition is handled by the launch that
+  // matches ITS type byte (the reference dispatches on partition 0 only).
+  // Undecodable headers are reported by the 1-byte launch.
+  const bool mine = bad_header || type > 7 ? (S == 1) : ((S == 1 && type <= 1) || (S == 2 && (type == 2 || type == 3))
+                                                        || (S == 4 && (type == 4 || type == 5))
+                                                        || (S == 8 && (type == 6 || type == 7)));
+  if (!mine)
+    return;
+  auto finish = [&](bool ok, uint32_t bytes) {
+    if (lane == 0) {
+      actual_bytes[part] = ok ? bytes : 0;
+      statuses[part] = ok ? hipcompSuccess : hipcompErrorCannotDecompress;
+    }
+  };
+  if (bad_header || type > 7) {
+    finish(false, 0);
+    return;
+  }
+  const uint32_t comp_bytes = (uint32_t)comp_bytes64;
+  const int R = comp[0], D = comp[1], bp = comp[2];
+  const uint32_t ub = *reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + 4);
+  const uint32_t N = ub / S;
+  gptr out = to_global(out_ptrs[part]);
+  if (out_caps[part] < (size_t)N * S) { // reference :1214-1223
+    finish(false, 0);
+    return;
+  }
+  if (R == 0 && D == 0 && bp == 0) { // raw partition (reference :1225-1254)
+    if (comp_bytes < ru(kPartMeta, S) + N * S) {
+      finish(false, 0);
+      return;
+    }
+    wave_copy(out, comp + ru(kPartMeta, S), N * S, lane);
+    finish(true, N * S);
+    return;
+  }
+  const uint32_t msz = chunk_metadata_size<S>(R, D);
+  if (R > 7 || msz > 64) {
+    finish(false, 0);
+    return;
+  }
+  uint8_t* my = smem + wave * wave_lds_bytes<S>();
+  UT* bufA = reinterpret_cast<UT*>(my);
+  UT* bufB = reinterpret_cast<UT*>(my + elem_buf_bytes());
+  uint16_t* cnts = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes());
+  uint32_t* meta = reinterpret_cast<uint32_t*>(my + 2 * elem_buf_bytes() + (kChunkBytes / S) * 2);
+
+  constexpr uint32_t CE = kChunkBytes / S;
+  const uint32_t end_w = comp_bytes / 4;
+  const uint32_t dh_off = ru((uint32_t)(4 + 4 * (R + 1)), (uint32_t)S);
+  const int layers = R > D ? R : D;
+  uint32_t pos = ru(kPartMeta, S), done = 0;
+  bool ok = true;
+  while (pos / 4 < end_w) { // reference :1268
+    if ((pos + msz) / 4 > end_w) {
+      ok = false;
+      break;
+    }
+    if ((uint32_t)lane < msz / 4)
+      meta[lane] = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + pos)[lane];
+    // array offsets inside the chunk (reference :1291-1305)
+    uint32_t offs_final = 0;
+    {
+      uint32_t o = 0;
+      for (int i = 0; i < R; ++i) {
+        const uint32_t sz = meta[i + 1];
+        o = ru(o + sz, (i == R - 1) ? (S > 4 ? (uint32_t)S : 4u) : 4u);
+      }
+      offs_final = o;
+    }
+    const uint32_t base = pos + msz;
+    UT* x = bufA;
+    UT* y = bufB;
+    int n = wave_read_array<UT>(comp, end_w, base + offs_final, meta[1 + R], bp, x, CE, lane);
+    if (n < 0) {
+      ok = false;
+      break;
+    }
+    // layers undone in the exact reverse of the encoder (see the oracle for
+    // the case num_deltas > num_RLEs where the reference's order is wrong)
+    for (int l = layers - 1; l >= 0 && ok; --l) {
+      if (l < D) { // reference block_delta_decompress :343-377
+        if ((uint32_t)n + 1 > CE) {
+          ok = false;
+          break;
+        }
+        UT carry = *reinterpret_cast<const UT*>(reinterpret_cast<const uint8_t*>(meta) + dh_off + l * S);
+        for (uint32_t b0 = 0; b0 < (uint32_t)n; b0 += kWave) {
+          const uint32_t i = b0 + (uint32_t)lane;
+          UT v = i < (uint32_t)n ? x[i] : (UT)0;
+          // inclusive scan over the 64 lanes
+          for (int o = 1; o < kWave; o <<= 1) {
+            const UT u = __shfl_up(v, o);
+            if (lane >= o)
+              v = (UT)(v + u);
+          }
+          const UT excl = (UT)(carry + v - (i < (uint32_t)n ? x[i] : (UT)0));
+          if (i < (uint32_t)n)
+            y[i] = excl;
+          carry = (UT)(carry + __shfl(v, kWave - 1));
+        }
+        if (lane == 0)
+          y[n] = carry;
+        UT* t = x; x = y; y = t;
+        ++n;
+      }
+      if (l < R) { // reference block_rle_decompress :255-305
+        uint32_t o = 0;
+        for (int i = 0; i < l; ++i)
+          o = ru(o + meta[i + 1], 4u);
+        const int m = wave_read_array<uint16_t>(comp, end_w, base + o, meta[l + 1], bp, cnts, CE, lane);
+        if (m < 0 || m != n) {
+          ok = false;
+          break;
+        }
+        // exclusive prefix of the run lengths, in place (start of each run)
+        uint32_t carry = 0;
+        bool too_long = false;
+        for (uint32_t b0 = 0; b0 < (uint32_t)n; b0 += kWave) {
+          const uint32_t i = b0 + (uint32_t)lane;
+          const uint32_t cv = i < (uint32_t)n ? cnts[i] : 0u;
+          uint32_t v = cv;
+          for (int o2 = 1; o2 < kWave; o2 <<= 1) {
+            const uint32_t u = __shfl_up(v, o2);
+            if (lane >= o2)
+              v += u;
+          }
+          const uint32_t start = carry + v - cv;
+          carry += __shfl(v, kWave - 1);
+          if (carry > CE) {
+            too_long = true;
+            break;
+          }
+          if (i < (uint32_t)n)
+            cnts[i] = (uint16_t)start;
+        }
+        if (too_long) {
+          ok = false;
+          break;
+        }
+        const uint32_t total = carry;
+        // expand: run of output j = last run whose start <= j
+        for (uint32_t j = (uint32_t)lane; j < total; j += kWave) {
+          uint32_t lo = 0, hi = (uint32_t)n - 1;
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (cnts[mid] <= j)
+              lo = mid;
+            else
+              hi = mid - 1;
+          }
+          y[j] = x[lo];
+        }
+        UT* t = x; x = y; y = t;
+        n = (int)total;
+      }
+    }
+    if (!ok)
+      break;
+    if (done + (uint32_t)n > N) { // reference :1395-1402
+      ok = false;
+      break;
+    }
+    // sub-chunk -> output
+    {
+      gptr dst = out + (size_t)done * S;
+      const uint32_t nb = (uint32_t)n * S;
+      const uint8_t* srcb = reinterpret_cast<const uint8_t*>(x);
+      if ((reinterpret_cast<uintptr_t>(dst) & 3u) == 0) {
+        const uint32_t words = nb / 4;
+        for (uint32_t w = (uint32_t)lane; w < words; w += kWave)
+          reinterpret_cast<HC_GLOBAL uint32_t*>(dst)[w] = reinterpret_cast<const uint32_t*>(srcb)[w];
+        for (uint32_t k = words * 4 + (uint32_t)lane; k < nb; k += kWave)
+          dst[k] = srcb[k];
+      } else {
+        for (uint32_t k = (uint32_t)lane; k < nb; k += kWave)
+          dst[k] = srcb[k];
+      }
+    }
+    done += (uint32_t)n;
+    const uint32_t csz = meta[0];
+    if (csz == 0) {
+      ok = false;
+      break;
+    }
+    pos = ru(pos + (csz / 4) * 4, S); // reference :1412-1413
+  }
+  if (done != N)
+    ok = false;
+  finish(ok, N * S);
+}
+
+__global__ __launch_bounds__(256) void cascaded_get_sizes_kernel(
+    const uint8_t* const* __restrict__ comp_ptrs,
+    const size_t* __restrict__ comp_bytes, size_t* __restrict__ out_sizes,
+    size_t batch)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch)
+    return;
+  size_t n = 0;
+  if (comp_bytes[i] >= kPartMeta) // reference CascadedBatch.hip:262-281
+    n = *reinterpret_cast<const HC_GLOBAL uint32_t*>(to_global(comp_ptrs[i]) + 4);
+  out_sizes[i] = n;
+}
+
+} // namespace
+
+void cascaded_launch_compress(
+    const uint8_t* const* in_ptrs, const size_t* in_bytes,
+    uint8_t* const* out_ptrs, size_t* out_bytes, size_t batch, int type_tag,
+    int elem_size, int num_rles, int num_deltas, int use_bp, hipStream_t stream)
+{
+  const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock));
+  const dim3 block(kWave * kWavesPerBlock);
+  switch (elem_size) {
+  case 1:
+    cascaded_compress_kernel<1><<<grid, block, 0, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, batch, type_tag, num_rles, num_deltas, use_bp);
+    break;
+  case 2:
+    cascaded_compress_kernel<2><<<grid, block, 0, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, batch, type_tag, num_rles, num_deltas, use_bp);
+    break;
+  case 4:
+    cascaded_compress_kernel<4><<<grid, block, 0, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, batch, type_tag, num_rles, num_deltas, use_bp);
+    break;
+  default:
+    cascaded_compress_kernel<8><<<grid, block, 0, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, batch, type_tag, num_rles, num_deltas, use_bp);
+    break;
+  }
+}
+
+void cascaded_launch_decompress(
+    const uint8_t* const* comp_ptrs, const size_t* comp_bytes,
+    const size_t* out_caps, size_t batch, uint8_t* const* out_ptrs,
+    size_t* actual_bytes, hipcompStatus_t* statuses, hipStream_t stream)
+{
+  const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock));
+  const dim3 block(kWave * kWavesPerBlock);
+  cascaded_decompress_kernel<4><<<grid, block, 0, stream>>>(
+      comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
+  cascaded_decompress_kernel<8><<<grid, block, 0, stream>>>(
+      comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
+  cascaded_decompress_kernel<2><<<grid, block, 0, stream>>>(
+      comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
+  cascaded_decompress_kernel<1><<<grid, block, 0, stream>>>(
+      comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
+}
+
+void cascaded_launch_get_sizes(
+    const uint8_t* const* comp_ptrs, const size_t* comp_bytes,
+    size_t* out_sizes, size_t batch, hipStream_t stream)
+{
+  cascaded_get_sizes_kernel<<<dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, stream>>>(
+      comp_ptrs, comp_bytes, out_sizes, batch);
+}
+
+} // namespace hcamd

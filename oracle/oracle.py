@@ -53,6 +53,15 @@ def lib():
         L.oracle_snappy_uncompressed_size.restype = c_size_t
         L.oracle_snappy_decompress.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t)]
         L.oracle_snappy_decompress.restype = c_int
+        L.oracle_cascaded_max_compressed_size.argtypes = [c_size_t]
+        L.oracle_cascaded_max_compressed_size.restype = c_size_t
+        L.oracle_cascaded_compress.argtypes = [c_char_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                               c_void_p, POINTER(c_size_t)]
+        L.oracle_cascaded_compress.restype = c_int
+        L.oracle_cascaded_decompressed_size.argtypes = [c_char_p, c_size_t]
+        L.oracle_cascaded_decompressed_size.restype = c_size_t
+        L.oracle_cascaded_decompress.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t)]
+        L.oracle_cascaded_decompress.restype = c_int
         _lib = L
     return _lib
 
@@ -123,3 +132,47 @@ def snappy_decompress(comp: bytes, capacity: int):
     n = c_size_t(0)
     st = lib().oracle_snappy_decompress(comp, len(comp), ctypes.cast(out, c_void_p), capacity, ctypes.byref(n))
     return st, out.raw[: n.value]
+
+
+# ---- Cascaded --------------------------------------------------------------
+
+CASCADED_TYPE_SIZE = {0: 1, 1: 1, 2: 2, 3: 2, 4: 4, 5: 4, 6: 8, 7: 8}
+
+
+def cascaded_max_compressed_size(n: int) -> int:
+    return lib().oracle_cascaded_max_compressed_size(n)
+
+
+def cascaded_compress(data: bytes, type_tag: int, num_rles: int, num_deltas: int, use_bp: int):
+    """-> (compressed bytes, mask bytes).  mask 0xFF = byte defined by the
+    format, 0x00 = don't-care byte (stale LDS / unwritten gap in the reference)."""
+    cap = cascaded_max_compressed_size(len(data))
+    out = ctypes.create_string_buffer(cap)
+    mask = ctypes.create_string_buffer(cap)
+    n = c_size_t(0)
+    rc = lib().oracle_cascaded_compress(data, len(data), type_tag, CASCADED_TYPE_SIZE[type_tag], num_rles, num_deltas,
+                                        use_bp, ctypes.cast(out, c_void_p), ctypes.cast(mask, c_void_p), ctypes.byref(n))
+    if rc != 0:
+        raise ValueError("oracle_cascaded_compress: unsupported options")
+    return out.raw[: n.value], mask.raw[: n.value]
+
+
+def cascaded_decompressed_size(comp: bytes) -> int:
+    return lib().oracle_cascaded_decompressed_size(comp, len(comp))
+
+
+def cascaded_decompress(comp: bytes, capacity: int):
+    out = ctypes.create_string_buffer(max(capacity, 1))
+    n = c_size_t(0)
+    st = lib().oracle_cascaded_decompress(comp, len(comp), ctypes.cast(out, c_void_p), capacity, ctypes.byref(n))
+    return st, out.raw[: n.value]
+
+
+def masked_equal(a: bytes, b: bytes, mask: bytes) -> bool:
+    if len(a) != len(b) or len(a) != len(mask):
+        return False
+    import numpy as np
+    x = np.frombuffer(a, dtype=np.uint8)
+    y = np.frombuffer(b, dtype=np.uint8)
+    m = np.frombuffer(mask, dtype=np.uint8)
+    return bool(np.all((x & m) == (y & m)))

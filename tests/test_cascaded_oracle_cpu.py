@@ -1,0 +1,115 @@
+"""The Cascaded CPU oracle against the wire-layout known answers of the
+reference's own test (tests/test_cascaded_batch.cpp:91-150, 213-379: two
+predefined inputs, {RLE=2, Delta=1, bp=0}, all eight integer types), the raw
+fallback header (:600-611), size-query behaviour (:950-990) and round trips."""
+import struct
+
+import numpy as np
+import pytest
+
+import datagen
+
+NP = {0: np.int8, 1: np.uint8, 2: np.int16, 3: np.uint16, 4: np.int32, 5: np.uint32, 6: np.int64, 7: np.uint64}
+
+
+def _ru(a, b):
+    return (a + b - 1) // b * b
+
+
+def _predefined(values, runs, t):
+    return np.repeat(np.array(values, dtype=NP[t]), runs).tobytes()
+
+
+@pytest.mark.parametrize("t", range(8))
+def test_reference_known_answers_layout(oracle, t):
+    s = oracle.CASCADED_TYPE_SIZE[t]
+    cases = [
+        (_predefined([3, 9, 4, 0, 1], [1, 20, 13, 25, 6], t), [1, 20, 13, 25, 6], [1, 1, 1, 1], [6, -5, -4, 1], 3),
+        (_predefined([1, 2, 3, 4, 5, 6], [10, 6, 15, 1, 13, 9], t), [10, 6, 15, 1, 13, 9], [5], [1], 1),
+    ]
+    for data, runs0, runs1, output, delta_value in cases:
+        comp, mask = oracle.cascaded_compress(data, t, 2, 1, 0)
+        assert len(comp) % 4 == 0 and len(comp) % s == 0
+        # partition header: 2 RLE, 1 delta, no bitpacking, the type (test :104-108)
+        assert struct.unpack_from("<I", comp, 0)[0] == 2 + (1 << 8) + (0 << 16) + (t << 24)
+        assert struct.unpack_from("<I", comp, 4)[0] == len(data)
+        cs = _ru(8, s)
+        sizes = struct.unpack_from("<4I", comp, cs)
+        assert sizes[1] == len(runs0) * 2 and sizes[2] == len(runs1) * 2 and sizes[3] == len(runs1) * s
+        dpos = _ru(cs + 16, s)
+        assert np.frombuffer(comp, dtype=NP[t], count=1, offset=dpos)[0] == NP[t](delta_value)
+        p = _ru(dpos + s, 4)
+        assert list(np.frombuffer(comp, dtype=np.uint16, count=len(runs0), offset=p)) == runs0
+        p = _ru(p + 2 * len(runs0), 4)
+        assert list(np.frombuffer(comp, dtype=np.uint16, count=len(runs1), offset=p)) == runs1
+        p = _ru(_ru(p + 2 * len(runs1), 4), s)
+        want = np.array(output).astype(NP[t])
+        assert list(np.frombuffer(comp, dtype=NP[t], count=len(output), offset=p)) == list(want)
+        # all the bytes the reference test reads are "meaningful" under the mask
+        assert mask[:8] == b"\xff" * 8
+        st, dec = oracle.cascaded_decompress(comp, len(data))
+        assert (st, dec) == (0, data)
+        # and with bitpacking the round trip holds too (test :382-384)
+        comp_bp, _ = oracle.cascaded_compress(data, t, 2, 1, 1)
+        assert oracle.cascaded_decompress(comp_bp, len(data)) == (0, data)
+
+
+def test_fallback_and_size_queries(oracle):
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 2**32, 1000, dtype=np.uint32).tobytes()   # incompressible
+    comp, mask = oracle.cascaded_compress(data, 5, 2, 1, 1)
+    assert comp[:4] == bytes([0, 0, 0, 5]) and len(comp) == 8 + len(data)   # header type<<24 (test :600-611)
+    assert comp[8:] == data
+    assert oracle.cascaded_decompress(comp, len(data)) == (0, data)
+    assert oracle.cascaded_decompressed_size(comp) == len(data)
+    assert oracle.cascaded_decompressed_size(comp[:4]) == 0                 # (test :950-990)
+    assert oracle.cascaded_decompress(comp[:4], 100) == (12, b"")
+    assert oracle.cascaded_decompress(comp, len(data) - 4)[0] == 12          # output too small (:794-814)
+    assert oracle.cascaded_decompress(comp[:-8], len(data))[0] == 12         # truncated input
+    assert oracle.cascaded_compress(b"", 5, 2, 1, 1) == (b"", b"")
+    assert oracle.cascaded_max_compressed_size(65536) == 65544
+    # explicit no-compression options
+    c0, _ = oracle.cascaded_compress(data, 5, 0, 0, 0)
+    assert c0 == comp
+
+
+def _sorted_column(seed, n):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, n)
+    inc = np.where(g == 0, 0, rng.integers(1, 9, n))
+    inc[0] = rng.integers(0, 1 << 20)
+    return np.cumsum(inc).astype(np.uint32)
+
+
+@pytest.mark.parametrize("opts", [(2, 1, 1), (2, 1, 0), (1, 0, 1), (0, 1, 1), (0, 0, 1), (1, 1, 0), (3, 2, 1), (2, 2, 1), (1, 2, 0)])
+def test_roundtrip_options_and_types(oracle, opts):
+    R, D, bp = opts
+    rng = np.random.default_rng(11)
+    for t in range(8):
+        dt = NP[t]
+        s = oracle.CASCADED_TYPE_SIZE[t]
+        inputs = [
+            _sorted_column(5, 16384).astype(dt).tobytes(),
+            np.repeat(rng.integers(0, 100, 300), rng.integers(1, 40, 300)).astype(dt).tobytes(),
+            np.zeros(5000, dtype=dt).tobytes(),                      # single-run sub-chunks -> empty layers
+            rng.integers(-100, 100, 3000).astype(dt).tobytes(),
+            np.arange(7, dtype=dt).tobytes(),
+            np.array([42], dtype=dt).tobytes(),
+        ]
+        for data in inputs:
+            comp, mask = oracle.cascaded_compress(data, t, R, D, bp)
+            assert len(comp) <= oracle.cascaded_max_compressed_size(len(data))
+            assert len(comp) % 4 == 0
+            st, dec = oracle.cascaded_decompress(comp, len(data))
+            assert (st, dec) == (0, data), (t, opts, len(data))
+            assert oracle.cascaded_decompressed_size(comp) == len(data)
+            # don't-care bytes really are don't-care for the decoder
+            noisy = bytes(b if m else 0xA5 for b, m in zip(comp, mask))
+            assert oracle.cascaded_decompress(noisy, len(data)) == (0, data)
+
+
+def test_trailing_partial_element_is_dropped(oracle):
+    data = np.arange(100, dtype=np.uint32).tobytes() + b"\x01\x02"      # 402 bytes, 100 elements
+    comp, _ = oracle.cascaded_compress(data, 5, 2, 1, 1)
+    assert oracle.cascaded_decompressed_size(comp) == 400
+    assert oracle.cascaded_decompress(comp, 402) == (0, data[:400])

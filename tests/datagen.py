@@ -87,3 +87,34 @@ def edge_chunks():
     out.append(("period3", (b"xyz" * 30000)[:65536]))
     out.append(("period1_then_rand", b"\x07" * 5000 + bytes(rng.integers(0, 256, 3000, dtype=np.uint8)) + b"\x07" * 9000))
     return out
+
+
+CASCADED_NP = {0: np.int8, 1: np.uint8, 2: np.int16, 3: np.uint16, 4: np.int32, 5: np.uint32, 6: np.int64, 7: np.uint64}
+
+
+def sorted_column(seed: int, n: int) -> np.ndarray:
+    """Sorted uint32 column, ~25 % repeats, increments 1..8."""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, n)
+    inc = np.where(g == 0, 0, rng.integers(1, 9, n))
+    inc[0] = rng.integers(0, 1 << 20)
+    return np.cumsum(inc).astype(np.uint32)
+
+
+def predefined(values, runs, t):
+    return np.repeat(np.array(values, dtype=CASCADED_NP[t]), runs).tobytes()
+
+
+def cascaded_golden_inputs(t: int):
+    """(name, bytes) inputs of tests/golden/cascaded_reference.json for type tag t."""
+    rng = np.random.default_rng(100 + t)
+    dt = CASCADED_NP[t]
+    return [
+        ("sorted", sorted_column(5 + t, 3000).astype(dt).tobytes()),
+        ("runs", np.repeat(rng.integers(0, 100, 120), rng.integers(1, 40, 120)).astype(dt).tobytes()),
+        ("zeros", np.zeros(1500, dtype=dt).tobytes()),
+        ("noise", rng.integers(-100, 100, 700).astype(dt).tobytes()),
+        ("incompressible", rng.integers(0, 2**31, 300).astype(dt).tobytes()),
+        ("predef0", predefined([3, 9, 4, 0, 1], [1, 20, 13, 25, 6], t)),
+        ("predef1", predefined([1, 2, 3, 4, 5, 6], [10, 6, 15, 1, 13, 9], t)),
+    ]

@@ -7,7 +7,7 @@ the reference's low-level sources compiled unmodified by oracle/Makefile):
 
 Inputs are regenerated from tests/datagen.py (seeded), so the fixture holds
 only the reference's OUTPUT: full compressed bytes for small chunks, SHA-256 +
-length for large ones.  The committed results are tests/golden/{lz4,snappy}_reference.json.
+length for large ones.  The committed results are tests/golden/{lz4,snappy,cascaded}_reference.json.
 """
 import base64
 import hashlib
@@ -78,6 +78,27 @@ def main(outdir):
     with open(os.path.join(outdir, "snappy_reference.json"), "w") as f:
         json.dump(sn, f, separators=(",", ":"))
     print("wrote", len(sn["snappy"]), "snappy records")
+
+    # ---- Cascaded: uint32/int16/uint8/int64 x three option sets; the reference's
+    # output carries don't-care bytes (stale LDS), so the FULL bytes are stored
+    # for every record and compared under the oracle's mask.
+    import zlib
+    import datagen
+    ca = {"generator": out["generator"], "library": out["library"], "device": out["device"],
+          "inputs": "tests/datagen.py:cascaded_golden_inputs(type)", "cascaded": []}
+    for t in (5, 2, 1, 6):
+        named_c = datagen.cascaded_golden_inputs(t)
+        csrc = hc.batch.from_host_chunks([c for _, c in named_c], "cuda:0")
+        for (R, D, bp) in ((2, 1, 1), (2, 1, 0), (1, 0, 1)):
+            comp = hc.batch.Codec("Cascaded", hc.CascadedOpts(4096, t, R, D, bp), lib=ref).compress(csrc)
+            torch.cuda.synchronize()
+            for (name, c), g in zip(named_c, comp.to_host_chunks()):
+                ca["cascaded"].append({"case": name, "type": t, "opts": [R, D, bp],
+                                       "in_sha256": hashlib.sha256(c).hexdigest(), "out_len": len(g),
+                                       "out_zb64": base64.b64encode(zlib.compress(g, 9)).decode()})
+    with open(os.path.join(outdir, "cascaded_reference.json"), "w") as f:
+        json.dump(ca, f, separators=(",", ":"))
+    print("wrote", len(ca["cascaded"]), "cascaded records")
 
 
 if __name__ == "__main__":

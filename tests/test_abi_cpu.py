@@ -94,3 +94,23 @@ def test_snappy_null_arguments(hc):
     assert lib.hipcompBatchedSnappyCompressAsync(None, None, 0, 1, None, 0, None, None, opts, None) == 10
     assert lib.hipcompBatchedSnappyDecompressAsync(None, None, None, None, 1, None, 0, None, None, None) == 10
     assert lib.hipcompBatchedSnappyGetDecompressSizeAsync(None, None, None, 1, None) == 10
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 65536, 65537])
+def test_cascaded_size_queries(hc, oracle, n):
+    lib = hc.default_library()
+    opts = hc.CascadedOpts(4096, hc.hipcompType.UINT, 2, 1, 1)
+    assert lib.max_output_chunk_size("Cascaded", n, opts) == (n + 3) // 4 * 4 + 8 == oracle.cascaded_max_compressed_size(n)
+    assert lib.compress_temp_size("Cascaded", 10, n, opts) == 0
+    assert lib.decompress_temp_size("Cascaded", 10, n) == 0
+
+
+def test_cascaded_null_arguments(hc):
+    lib = hc.default_library()
+    opts = hc.CascadedOpts(4096, 5, 2, 1, 1)
+    assert lib.hipcompBatchedCascadedCompressGetTempSize(1, 1, opts, None) == 10
+    assert lib.hipcompBatchedCascadedCompressGetMaxOutputChunkSize(1, opts, None) == 10
+    assert lib.hipcompBatchedCascadedDecompressGetTempSize(1, 1, None) == 10
+    assert lib.hipcompBatchedCascadedCompressAsync(None, None, 0, 1, None, 0, None, None, opts, None) == 10
+    assert lib.hipcompBatchedCascadedGetDecompressSizeAsync(None, None, None, 1, None) == 10
+    assert lib.max_output_chunk_size("Cascaded", 65536, opts) == 65544

@@ -9,15 +9,14 @@ import pytest
 
 import datagen
 
-NP = {0: np.int8, 1: np.uint8, 2: np.int16, 3: np.uint16, 4: np.int32, 5: np.uint32, 6: np.int64, 7: np.uint64}
+NP = datagen.CASCADED_NP
 
 
 def _ru(a, b):
     return (a + b - 1) // b * b
 
 
-def _predefined(values, runs, t):
-    return np.repeat(np.array(values, dtype=NP[t]), runs).tobytes()
+_predefined = datagen.predefined
 
 
 @pytest.mark.parametrize("t", range(8))
@@ -73,12 +72,7 @@ def test_fallback_and_size_queries(oracle):
     assert c0 == comp
 
 
-def _sorted_column(seed, n):
-    rng = np.random.default_rng(seed)
-    g = rng.integers(0, 4, n)
-    inc = np.where(g == 0, 0, rng.integers(1, 9, n))
-    inc[0] = rng.integers(0, 1 << 20)
-    return np.cumsum(inc).astype(np.uint32)
+_sorted_column = datagen.sorted_column
 
 
 @pytest.mark.parametrize("opts", [(2, 1, 1), (2, 1, 0), (1, 0, 1), (0, 1, 1), (0, 0, 1), (1, 1, 0), (3, 2, 1), (2, 2, 1), (1, 2, 0)])

@@ -18,8 +18,9 @@
 //   copied out word by word                   the LDS element array to HBM
 //   decompress: 4 launches, type taken from   4 launches (LDS sized per
 //   partition 0, RLE expand = 1 thread/run    width), type taken from EACH
-//                                             partition; RLE expand = binary
-//                                             search per output element
+//   (a 4096-long run = 4096 serial stores)    partition; RLE expand = run
+//                                             markers + DPP running max;
+//                                             delta = DPP prefix sum
 //
 // Bytes the reference leaves undefined (stale LDS / unwritten gaps,
 // SURVEY.md App. C.4) are written as 0 here, so the output is deterministic.
@@ -50,8 +51,19 @@ __host__ __device__ constexpr uint32_t elem_buf_bytes() { return kChunkBytes + 1
 template <int S>
 __host__ __device__ constexpr uint32_t wave_lds_bytes()
 {
-  // two element buffers + one run-count array + 64-byte chunk-metadata image
+  // encoder: two element buffers + run-count array + 64-byte metadata image
   return 2 * elem_buf_bytes() + (kChunkBytes / S) * 2 + 64;
+}
+
+// decoder: the compressed sub-chunk (metadata + arrays) is staged in LDS,
+// kStageWords 32-bit words per sub-chunk, 8 per lane, loaded one sub-chunk
+// ahead into registers.  Arrays that do not fit are read from HBM directly.
+constexpr uint32_t kStageWords = 8 * kWave; // 2 KiB
+template <int S>
+__host__ __device__ constexpr uint32_t dec_lds_bytes()
+{
+  // two element buffers + run starts + run markers + staged sub-chunk
+  return 2 * elem_buf_bytes() + 2 * (kChunkBytes / S) * 2 + kStageWords * 4;
 }
 
 // ---- wave reductions (64 lanes) -------------------------------------------
@@ -337,39 +349,34 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
 // Decoder
 // ---------------------------------------------------------------------------
 
-// One array from HBM into LDS (reference block_read :702-737 +
-// block_bitunpack :563-618).  Returns the element count, or -1 when the array
-// leaves the partition / the sub-chunk.
-template <typename ET>
-__device__ __forceinline__ int wave_read_array(
-    cgptr comp, uint32_t end_words, uint32_t off, uint32_t nbytes, int bp,
-    ET* dst, uint32_t max_elems, int lane)
+// One array into an LDS element buffer (reference block_read :702-737 +
+// block_bitunpack :563-618).  `src` are the array's 32-bit words, either in
+// the staged LDS image or in HBM.  Returns the element count, or -1 when the
+// array leaves the sub-chunk buffer.
+template <typename ET, typename WordPtr>
+__device__ __forceinline__ int unpack_array(
+    WordPtr src, uint32_t nbytes, int bp, ET* dst, uint32_t max_elems, int lane)
 {
   constexpr uint32_t ES = sizeof(ET);
-  if ((off & 3u) || (off + ru(nbytes, 4)) / 4 > end_words)
-    return -1;
   if (!bp) {
     const uint32_t n = nbytes / ES;
     if (n > max_elems)
       return -1;
     const uint32_t words = (n * ES + 3) / 4;
-    const HC_GLOBAL uint32_t* src = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off);
     uint32_t* d = reinterpret_cast<uint32_t*>(dst);
     for (uint32_t w = (uint32_t)lane; w < words; w += kWave)
       d[w] = src[w];
     return (int)n;
   }
-  constexpr uint32_t HDR = ES > 4 ? 16 : 8;
-  constexpr uint32_t WOFF = ES > 4 ? 8 : 4;
-  if (nbytes < HDR)
+  constexpr uint32_t HDRW = ES > 4 ? 4 : 2; // header words
+  if (nbytes < HDRW * 4)
     return -1;
   ET fr;
   if (ES > 4)
-    fr = (ET)((uint64_t)*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off)
-              | ((uint64_t)*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off + 4) << 32));
+    fr = (ET)((uint64_t)src[0] | ((uint64_t)src[1] << 32));
   else
-    fr = (ET)*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off);
-  const uint32_t word = *reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off + WOFF);
+    fr = (ET)src[0];
+  const uint32_t word = src[ES > 4 ? 2 : 1];
   const uint32_t bw = word >> 16;
   const uint32_t n = word & 0xFFFFu;
   if (n == 0)
@@ -377,9 +384,9 @@ __device__ __forceinline__ int wave_read_array(
   if (n > max_elems || bw > 8 * ES)
     return -1;
   const uint32_t words = (n * bw + 31) / 32;
-  if (HDR + 4 * words > ru(nbytes, 4))
+  if (HDRW * 4 + 4 * words > ru(nbytes, 4))
     return -1;
-  const HC_GLOBAL uint32_t* data = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off + HDR);
+  WordPtr data = src + HDRW;
   for (uint32_t i = (uint32_t)lane; i < n; i += kWave) {
     ET x = 0;
     if (bw) {
@@ -398,8 +405,25 @@ __device__ __forceinline__ int wave_read_array(
   return (int)n;
 }
 
+// Array at byte offset `rel` of the sub-chunk that starts at comp + pos:
+// bounds as in the reference (:712-713), source = staged image when the array
+// lies inside it.
+template <typename ET>
+__device__ __forceinline__ int wave_read_array(
+    cgptr comp, uint32_t end_words, uint32_t pos, uint32_t rel, uint32_t nbytes,
+    int bp, const uint32_t* stage, ET* dst, uint32_t max_elems, int lane)
+{
+  const uint32_t off = pos + rel;
+  if ((off & 3u) || (off + ru(nbytes, 4)) / 4 > end_words)
+    return -1;
+  if (rel + ru(nbytes, 4) <= kStageWords * 4)
+    return unpack_array<ET>(stage + rel / 4, nbytes, bp, dst, max_elems, lane);
+  return unpack_array<ET>(reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off), nbytes, bp, dst,
+                          max_elems, lane);
+}
+
 template <int S>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_decompress_kernel(
+__global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
     const uint8_t* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes_arr,
     const size_t* __restrict__ out_caps, const size_t batch,
@@ -407,10 +431,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_decompress_ke
     hipcompStatus_t* __restrict__ statuses)
 {
   typedef typename UIntOf<S>::type UT;
-  __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * wave_lds_bytes<S>()];
+  __shared__ __attribute__((aligned(16))) uint8_t smem[dec_lds_bytes<S>()];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
-  const size_t part = (size_t)blockIdx.x * kWavesPerBlock + wave;
+  const size_t part = blockIdx.x;
   if (part >= batch)
     return;
   cgptr comp = to_global(comp_ptrs[part]);
@@ -460,11 +483,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_decompress_ke
     finish(false, 0);
     return;
   }
-  uint8_t* my = smem + wave * wave_lds_bytes<S>();
+  uint8_t* my = smem;
   UT* bufA = reinterpret_cast<UT*>(my);
   UT* bufB = reinterpret_cast<UT*>(my + elem_buf_bytes());
   uint16_t* cnts = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes());
-  uint32_t* meta = reinterpret_cast<uint32_t*>(my + 2 * elem_buf_bytes() + (kChunkBytes / S) * 2);
+  uint16_t* marks = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes() + (kChunkBytes / S) * 2);
+  uint32_t* stage = reinterpret_cast<uint32_t*>(my + 2 * elem_buf_bytes() + 2 * (kChunkBytes / S) * 2);
+  const uint32_t* meta = stage; // the chunk metadata is the head of the staged image
 
   constexpr uint32_t CE = kChunkBytes / S;
   const uint32_t end_w = comp_bytes / 4;
@@ -472,13 +497,36 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_decompress_ke
   const int layers = R > D ? R : D;
   uint32_t pos = ru(kPartMeta, S), done = 0;
   bool ok = true;
+  // kStageWords words of the sub-chunk at `p`, 8 per lane, clipped to the
+  // partition (words past the end read as 0); issued one sub-chunk ahead
+  uint32_t pf[8];
+  auto prefetch = [&](uint32_t p) {
+    const HC_GLOBAL uint32_t* w = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + p);
+    const uint32_t avail = end_w - p / 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t idx = (uint32_t)lane + (uint32_t)k * kWave;
+      pf[k] = w[min(idx, avail - 1)];
+    }
+  };
+  if (pos / 4 < end_w)
+    prefetch(pos);
   while (pos / 4 < end_w) { // reference :1268
     if ((pos + msz) / 4 > end_w) {
       ok = false;
       break;
     }
-    if ((uint32_t)lane < msz / 4)
-      meta[lane] = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + pos)[lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      stage[lane + k * kWave] = pf[k];
+    const uint32_t csz = meta[0];
+    if (csz == 0) {
+      ok = false;
+      break;
+    }
+    const uint32_t next_pos = ru(pos + (csz / 4) * 4, S); // reference :1412-1413
+    if (next_pos / 4 < end_w)
+      prefetch(next_pos);
     // array offsets inside the chunk (reference :1291-1305)
     uint32_t offs_final = 0;
     {
@@ -489,36 +537,45 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_decompress_ke
       }
       offs_final = o;
     }
-    const uint32_t base = pos + msz;
     UT* x = bufA;
     UT* y = bufB;
-    int n = wave_read_array<UT>(comp, end_w, base + offs_final, meta[1 + R], bp, x, CE, lane);
+    int n = wave_read_array<UT>(comp, end_w, pos, msz + offs_final, meta[1 + R], bp, stage, x, CE, lane);
     if (n < 0) {
       ok = false;
       break;
     }
-    // layers undone in the exact reverse of the encoder (see the oracle for
-    // the case num_deltas > num_RLEs where the reference's order is wrong)
+    // Layers undone in the exact reverse of the encoder (see the oracle for
+    // the case num_deltas > num_RLEs where the reference's order is wrong).
+    // Two fusions keep the passes over LDS short: an RLE expansion whose
+    // output feeds a delta layer does the prefix sum in the same pass, and the
+    // last expansion of a sub-chunk stores straight to HBM.
+    bool stored = false;      // sub-chunk already written to the output
+    int fused_delta = -1;     // delta layer already undone by a fused expansion
     for (int l = layers - 1; l >= 0 && ok; --l) {
-      if (l < D) { // reference block_delta_decompress :343-377
+      if (l < D && l != fused_delta) { // reference block_delta_decompress :343-377
         if ((uint32_t)n + 1 > CE) {
           ok = false;
           break;
         }
         UT carry = *reinterpret_cast<const UT*>(reinterpret_cast<const uint8_t*>(meta) + dh_off + l * S);
+
         for (uint32_t b0 = 0; b0 < (uint32_t)n; b0 += kWave) {
           const uint32_t i = b0 + (uint32_t)lane;
-          UT v = i < (uint32_t)n ? x[i] : (UT)0;
-          // inclusive scan over the 64 lanes
-          for (int o = 1; o < kWave; o <<= 1) {
-            const UT u = __shfl_up(v, o);
-            if (lane >= o)
-              v = (UT)(v + u);
-          }
-          const UT excl = (UT)(carry + v - (i < (uint32_t)n ? x[i] : (UT)0));
+          const UT own = i < (uint32_t)n ? x[i] : (UT)0;
+          UT incl;
+          if (S > 4)
+            incl = (UT)wave_scan_add_u64((uint64_t)own);
+          else
+            incl = (UT)wave_scan_add_u32((uint32_t)own);
           if (i < (uint32_t)n)
-            y[i] = excl;
-          carry = (UT)(carry + __shfl(v, kWave - 1));
+            y[i] = (UT)(carry + incl - own);
+          if (S > 4) {
+            const uint64_t tot = (uint64_t)read_lane((uint32_t)((uint64_t)incl), 63)
+                                 | ((uint64_t)read_lane((uint32_t)((uint64_t)incl >> 32), 63) << 32);
+            carry = (UT)(carry + (UT)tot);
+          } else {
+            carry = (UT)(carry + (UT)read_lane((uint32_t)incl, 63));
+          }
         }
         if (lane == 0)
           y[n] = carry;
@@ -529,61 +586,104 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_decompress_ke
         uint32_t o = 0;
         for (int i = 0; i < l; ++i)
           o = ru(o + meta[i + 1], 4u);
-        const int m = wave_read_array<uint16_t>(comp, end_w, base + o, meta[l + 1], bp, cnts, CE, lane);
+        const int m = wave_read_array<uint16_t>(comp, end_w, pos, msz + o, meta[l + 1], bp, stage, cnts, CE, lane);
         if (m < 0 || m != n) {
           ok = false;
           break;
         }
-        // exclusive prefix of the run lengths, in place (start of each run)
+        // Each run drops its index+1 at its start position (exclusive prefix
+        // of the lengths) in `marks`; a running max over the positions then
+        // names the run of every output element.
+        {
+          u32x4 z = {0, 0, 0, 0};
+          u32x4* mz = reinterpret_cast<u32x4*>(marks);
+          for (uint32_t k = (uint32_t)lane; k < CE * 2 / 16; k += kWave)
+            mz[k] = z;
+        }
         uint32_t carry = 0;
         bool too_long = false;
         for (uint32_t b0 = 0; b0 < (uint32_t)n; b0 += kWave) {
           const uint32_t i = b0 + (uint32_t)lane;
           const uint32_t cv = i < (uint32_t)n ? cnts[i] : 0u;
-          uint32_t v = cv;
-          for (int o2 = 1; o2 < kWave; o2 <<= 1) {
-            const uint32_t u = __shfl_up(v, o2);
-            if (lane >= o2)
-              v += u;
-          }
-          const uint32_t start = carry + v - cv;
-          carry += __shfl(v, kWave - 1);
-          if (carry > CE) {
-            too_long = true;
-            break;
-          }
-          if (i < (uint32_t)n)
-            cnts[i] = (uint16_t)start;
+          const uint32_t incl = wave_scan_add_u32(cv);
+          const uint32_t start = carry + incl - cv;
+          carry += read_lane(incl, 63);
+          if (i < (uint32_t)n && start < CE)
+            marks[start] = (uint16_t)(i + 1);
+          too_long = too_long || carry > CE;
         }
         if (too_long) {
           ok = false;
           break;
         }
         const uint32_t total = carry;
-        // expand: run of output j = last run whose start <= j
-        for (uint32_t j = (uint32_t)lane; j < total; j += kWave) {
-          uint32_t lo = 0, hi = (uint32_t)n - 1;
-          while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) >> 1;
-            if (cnts[mid] <= j)
-              lo = mid;
-            else
-              hi = mid - 1;
-          }
-          y[j] = x[lo];
+        const bool with_delta = l >= 1 && (l - 1) < D; // next op: delta of layer l-1
+        const bool to_hbm = l == 0 && S >= 4;          // last op of the sub-chunk
+        if (with_delta && total + 1 > CE) {
+          ok = false;
+          break;
         }
+        if (to_hbm && done + total > N) { // reference :1395-1402
+          ok = false;
+          break;
+        }
+        UT head = 0;
+        if (with_delta)
+          head = *reinterpret_cast<const UT*>(reinterpret_cast<const uint8_t*>(meta) + dh_off + (l - 1) * S);
+        HC_GLOBAL UT* gdst = reinterpret_cast<HC_GLOBAL UT*>(out + (size_t)done * S);
+        uint32_t run_carry = 0;
+        UT sum_carry = head;
+#pragma unroll 2
+        for (uint32_t b0 = 0; b0 < total; b0 += kWave) {
+          const uint32_t j = b0 + (uint32_t)lane;
+          const uint32_t mk = j < total ? marks[j] : 0u;
+          uint32_t r = wave_scan_max_u32(mk);
+          r = r > run_carry ? r : run_carry;
+          run_carry = read_lane(r, 63);
+          UT v = j < total ? x[r - 1] : (UT)0;
+          if (with_delta) {
+            UT incl;
+            if (S > 4) {
+              incl = (UT)wave_scan_add_u64((uint64_t)v);
+              const uint64_t tot = (uint64_t)read_lane((uint32_t)((uint64_t)incl), 63)
+                                   | ((uint64_t)read_lane((uint32_t)((uint64_t)incl >> 32), 63) << 32);
+              v = (UT)(sum_carry + incl);
+              sum_carry = (UT)(sum_carry + (UT)tot);
+            } else {
+              incl = (UT)wave_scan_add_u32((uint32_t)v);
+              v = (UT)(sum_carry + incl);
+              sum_carry = (UT)(sum_carry + (UT)read_lane((uint32_t)incl, 63));
+            }
+            if (j < total)
+              y[j + 1] = v;
+          } else if (to_hbm) {
+            if (j < total)
+              gdst[j] = v;
+          } else {
+            if (j < total)
+              y[j] = v;
+          }
+        }
+        if (with_delta) {
+          if (lane == 0)
+            y[0] = head;
+          fused_delta = l - 1;
+          n = (int)total + 1;
+        } else {
+          n = (int)total;
+        }
+        stored = to_hbm;
         UT* t = x; x = y; y = t;
-        n = (int)total;
       }
     }
     if (!ok)
       break;
-    if (done + (uint32_t)n > N) { // reference :1395-1402
-      ok = false;
-      break;
-    }
-    // sub-chunk -> output
-    {
+    if (!stored) {
+      if (done + (uint32_t)n > N) { // reference :1395-1402
+        ok = false;
+        break;
+      }
+      // sub-chunk -> output
       gptr dst = out + (size_t)done * S;
       const uint32_t nb = (uint32_t)n * S;
       const uint8_t* srcb = reinterpret_cast<const uint8_t*>(x);
@@ -599,12 +699,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_decompress_ke
       }
     }
     done += (uint32_t)n;
-    const uint32_t csz = meta[0];
-    if (csz == 0) {
-      ok = false;
-      break;
-    }
-    pos = ru(pos + (csz / 4) * 4, S); // reference :1412-1413
+    pos = next_pos;
   }
   if (done != N)
     ok = false;
@@ -659,8 +754,8 @@ void cascaded_launch_decompress(
     const size_t* out_caps, size_t batch, uint8_t* const* out_ptrs,
     size_t* actual_bytes, hipcompStatus_t* statuses, hipStream_t stream)
 {
-  const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock));
-  const dim3 block(kWave * kWavesPerBlock);
+  const dim3 grid((unsigned)batch);
+  const dim3 block(kWave);
   cascaded_decompress_kernel<4><<<grid, block, 0, stream>>>(
       comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
   cascaded_decompress_kernel<8><<<grid, block, 0, stream>>>(

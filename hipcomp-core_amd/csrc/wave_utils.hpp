@@ -60,6 +60,59 @@ __device__ __forceinline__ uint64_t low_lanes_mask(int n) // lanes [0, n)
   return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
 }
 
+// ---- wave64 inclusive scans on the DPP crossbar (no LDS, no ds_bpermute) ---
+// row_shr:1,2,4,8 scans each 16-lane row, row_bcast:15 / row_bcast:31 carry
+// the row totals into the following rows (gfx9 DPP controls).  Lanes shifted
+// in from outside a row read 0, the identity of both operations on unsigned
+// values.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v)
+{
+  v += dpp_u32<0x111, 0xF>(v); // row_shr:1
+  v += dpp_u32<0x112, 0xF>(v); // row_shr:2
+  v += dpp_u32<0x114, 0xF>(v); // row_shr:4
+  v += dpp_u32<0x118, 0xF>(v); // row_shr:8
+  v += dpp_u32<0x142, 0xA>(v); // row_bcast:15 -> rows 1, 3
+  v += dpp_u32<0x143, 0xC>(v); // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v)
+{
+  uint32_t u;
+  u = dpp_u32<0x111, 0xF>(v); v = u > v ? u : v;
+  u = dpp_u32<0x112, 0xF>(v); v = u > v ? u : v;
+  u = dpp_u32<0x114, 0xF>(v); v = u > v ? u : v;
+  u = dpp_u32<0x118, 0xF>(v); v = u > v ? u : v;
+  u = dpp_u32<0x142, 0xA>(v); v = u > v ? u : v;
+  u = dpp_u32<0x143, 0xC>(v); v = u > v ? u : v;
+  return v;
+}
+
+__device__ __forceinline__ uint64_t wave_scan_add_u64(uint64_t v)
+{
+  // 64-bit sums: two 32-bit DPP moves per step
+#define HC_STEP(CTRL, MASK)                                                      \
+  {                                                                              \
+    const uint64_t u = (uint64_t)dpp_u32<CTRL, MASK>((uint32_t)v)                \
+                       | ((uint64_t)dpp_u32<CTRL, MASK>((uint32_t)(v >> 32)) << 32); \
+    v += u;                                                                      \
+  }
+  HC_STEP(0x111, 0xF)
+  HC_STEP(0x112, 0xF)
+  HC_STEP(0x114, 0xF)
+  HC_STEP(0x118, 0xF)
+  HC_STEP(0x142, 0xA)
+  HC_STEP(0x143, 0xC)
+#undef HC_STEP
+  return v;
+}
+
 // Copy n bytes dst <- src with all 64 lanes; any alignment on either side,
 // regions must not overlap.  16-byte aligned stores, unaligned 16-byte loads.
 __device__ __forceinline__ void wave_copy(

@@ -118,3 +118,68 @@ def cascaded_golden_inputs(t: int):
         ("predef0", predefined([3, 9, 4, 0, 1], [1, 20, 13, 25, 6], t)),
         ("predef1", predefined([1, 2, 3, 4, 5, 6], [10, 6, 15, 1, 13, 9], t)),
     ]
+
+
+# ---- TPC-H lineitem-like text (BASELINE.json configs[3]) --------------------
+# No dbgen and no network here: a deterministic generator that follows the
+# lineitem column grammar of the TPC-H specification (clause 4.2.3): keys,
+# quantities, decimal prices, flags, three dates, ship instructions / modes and
+# a comment built from the spec's word lists, fields separated by "|".
+_TPCH_INSTRUCT = ["DELIVER IN PERSON", "COLLECT COD", "NONE", "TAKE BACK RETURN"]
+_TPCH_MODES = ["REG AIR", "AIR", "RAIL", "SHIP", "TRUCK", "MAIL", "FOB"]
+_TPCH_WORDS = ("furiously sly carefully blithely quickly fluffily slyly quietly ruthlessly thinly closely doggedly "
+               "daringly bravely stealthily permanently enticingly idly busily regular final ironic even bold silent "
+               "special pending unusual express packages requests accounts deposits foxes ideas theodolites pinto beans "
+               "instructions dependencies excuses platelets asymptotes courts dolphins multipliers sauternes warthogs "
+               "frets dinos attainments somas Tiresias patterns forges braids hockey players frays warhorses dugouts "
+               "notornis epitaphs pearls tithes waters orbits gifts sheaves depths sentiments decoys realms pains "
+               "grouches escapades sleep wake are cajole haggle nag use boost affix detect integrate maintain nod was "
+               "lose sublate solve thrash promise engage hinder print x-ray breach eat grow impress mold poach serve run "
+               "dazzle snooze doze unwind kindle play hang believe doubt about above according to across after against "
+               "along alongside of among around at atop before behind beneath beside besides between beyond by despite "
+               "during except for from in place of inside instead of into near of on outside over past since through "
+               "throughout to toward under until up upon without with within").split()
+
+
+def tpch_lineitem_text(seed: int, n_bytes: int) -> bytes:
+    rng = np.random.default_rng(seed)
+    rows = n_bytes // 100 + 64
+    okey = np.cumsum(rng.integers(0, 2, rows) * rng.integers(1, 5, rows)) + 1
+    line = np.ones(rows, dtype=np.int64)
+    for i in range(1, 8):  # line numbers 1..7 within an order
+        same = np.zeros(rows, dtype=bool)
+        same[i:] = okey[i:] == okey[:-i]
+        line = np.where(same, np.maximum(line, i + 1), line)
+    part = rng.integers(1, 200001, rows)
+    supp = rng.integers(1, 10001, rows)
+    qty = rng.integers(1, 51, rows)
+    price = qty * (90000 + (part // 10) % 20001 + 100 * (part % 1000))  # cents
+    disc = rng.integers(0, 11, rows)
+    tax = rng.integers(0, 9, rows)
+    day0 = rng.integers(0, 2406, rows)  # days since 1992-01-02
+    base = np.datetime64("1992-01-02")
+    ship = (base + day0).astype(str)
+    commit = (base + day0 + rng.integers(-60, 61, rows)).astype(str)
+    receipt = (base + day0 + rng.integers(1, 31, rows)).astype(str)
+    rflag = np.where(day0 > 1260, "N", np.where(rng.integers(0, 2, rows) == 0, "R", "A"))
+    lstat = np.where(day0 > 1260, "O", "F")
+    instr = np.array(_TPCH_INSTRUCT)[rng.integers(0, 4, rows)]
+    mode = np.array(_TPCH_MODES)[rng.integers(0, 7, rows)]
+    words = np.array(_TPCH_WORDS)
+    nw = rng.integers(2, 7, rows)
+    comment = words[rng.integers(0, len(words), rows)]
+    for k in range(1, 6):
+        extra = np.char.add(" ", words[rng.integers(0, len(words), rows)])
+        comment = np.where(nw > k, np.char.add(comment, extra), comment)
+    def dec(v):  # cents -> "123.45"
+        return np.char.add(np.char.add((v // 100).astype(str), "."), np.char.zfill((v % 100).astype(str), 2))
+    cols = [okey.astype(str), part.astype(str), supp.astype(str), line.astype(str), qty.astype(str), dec(price),
+            np.char.add("0.", np.char.zfill(disc.astype(str), 2)), np.char.add("0.", np.char.zfill(tax.astype(str), 2)),
+            rflag, lstat, ship, commit, receipt, instr, mode, comment]
+    row = cols[0]
+    for c in cols[1:]:
+        row = np.char.add(np.char.add(row, "|"), c)
+    text = "\n".join(row.tolist()).encode() + b"\n"
+    while len(text) < n_bytes:
+        text += text
+    return text[:n_bytes]

@@ -633,7 +633,6 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
         HC_GLOBAL UT* gdst = reinterpret_cast<HC_GLOBAL UT*>(out + (size_t)done * S);
         uint32_t run_carry = 0;
         UT sum_carry = head;
-#pragma unroll 2
         for (uint32_t b0 = 0; b0 < total; b0 += kWave) {
           const uint32_t j = b0 + (uint32_t)lane;
           const uint32_t mk = j < total ? marks[j] : 0u;

@@ -60,6 +60,15 @@ __device__ __forceinline__ uint32_t write_sequence(
     gptr comp, uint32_t c, cgptr lit_src, uint32_t lit_bytes,
     uint32_t match_bytes, uint32_t offset_bytes, int lane)
 {
+#ifdef HC_ABL_NO_STORES
+  {
+    uint32_t cc = c + 1;
+    if (lit_bytes >= 15) cc += (lit_bytes - 15u) / 255u + 1u;
+    cc += lit_bytes;
+    if (match_bytes > 0) { cc += 2; if (match_bytes >= 19) cc += (match_bytes - 19u) / 255u + 1u; }
+    return cc;
+  }
+#endif
   if (lane == 0) {
     const uint32_t lh = lit_bytes >= 15 ? 15u : lit_bytes;
     const uint32_t mh = match_bytes >= 19 ? 15u : ((match_bytes - 4u) & 0x0fu);
@@ -271,7 +280,11 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
       // whose byte distance does not fit are rejected here; for chunks
       // <= 64 KiB this never triggers, so those stay bit-identical
       // (DESIGN.md "deliberate deviations").
+#ifdef HC_ABL_NO_VERIFY
+      const bool probe = false;
+#else
       const bool probe = h_old != kNullOffset && dist * S <= 65535u && dist <= 65535u;
+#endif
       const uint32_t cand_word
           = load_u32_any(in + (size_t)(probe ? cand : min(pos, last_word)) * S);
 
@@ -293,16 +306,16 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
       {
         const uint32_t packed = hpos | (valid ? 0x80000000u : 0u);
         const uint32_t pr = (uint32_t)__builtin_amdgcn_ds_bpermute(rev_addr4, (int)packed);
-        // (volatile: these values travel between lanes through LDS; the
-        // compiler must neither forward nor reorder them)
-        volatile uint16_t* vtable = table;
+        lds_lane_exchange_fence();
         if (pr & 0x80000000u)
-          vtable[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
+          table[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
+        lds_lane_exchange_fence();
       }
-      volatile uint16_t* vtable = table;
-      const uint32_t w = valid ? (uint32_t)vtable[hpos] : (uint32_t)lane;
+      const uint32_t w = valid ? (uint32_t)table[hpos] : (uint32_t)lane;
+      lds_lane_exchange_fence();
       if (valid)
-        vtable[hpos] = (uint16_t)h_old;
+        table[hpos] = (uint16_t)h_old;
+      lds_lane_exchange_fence();
       const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)next);
       // masks are combined as scalars: each ballot is one v_cmp
       const uint64_t vmask = low_lanes_mask(nv);

@@ -124,12 +124,13 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
       // HashMatchAny (reference :157-172): all 64 lanes take part, lanes past
       // the end with hash 0.  Post lane ids (highest lane survives), read the
       // slot back, restore it.
-      // (volatile: the values travel between lanes through LDS, which the
-      // compiler must not forward from this lane's own store)
-      volatile uint16_t* vmap = hash_map;
-      vmap[hash] = (uint16_t)lane;
-      const uint32_t top = vmap[hash];
-      vmap[hash] = (uint16_t)h_old;
+      lds_lane_exchange_fence();
+      hash_map[hash] = (uint16_t)lane;
+      lds_lane_exchange_fence();
+      const uint32_t top = hash_map[hash];
+      lds_lane_exchange_fence();
+      hash_map[hash] = (uint16_t)h_old;
+      lds_lane_exchange_fence();
       uint64_t local_match = lane_bit;
       uint64_t pending = wave_ballot(top != (uint32_t)lane); // lanes in slots with >= 2 lanes
       while (pending) {

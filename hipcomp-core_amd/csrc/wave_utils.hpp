@@ -48,6 +48,17 @@ __device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane)
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
+// Compiler-only fence for LDS traffic that travels BETWEEN lanes of the wave
+// (one lane stores, another lane loads the same address in the next
+// instruction).  LDS operations of a wave execute in order, so no hardware
+// wait is needed, but the compiler must neither forward this lane's own store
+// to its load nor reorder the accesses.  (A `volatile` pointer would do that
+// too, but it turns the ds_* accesses into flat_* ones with full waits.)
+__device__ __forceinline__ void lds_lane_exchange_fence()
+{
+  asm volatile("" ::: "memory");
+}
+
 // 64-bit ballot straight from the condition (HIP's __ballot goes through a
 // VGPR 0/1 value and a second compare).
 __device__ __forceinline__ uint64_t wave_ballot(bool p)

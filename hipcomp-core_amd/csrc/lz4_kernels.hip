@@ -35,14 +35,7 @@ namespace hcamd {
 namespace {
 
 constexpr uint32_t kNullOffset = 0xFFFFu;
-// Measure short matches from registers (16-byte candidate loads) instead of a
-// second trip to memory.  Measured on MI355X: +4..5 % on data with 5-7 byte
-// matches, -10 % on incompressible data (wider gather), -27 % on long matches;
-// kept off.
-#ifndef HC_LZ4_REG_MATCH_LEN
-#define HC_LZ4_REG_MATCH_LEN 0
-#endif
-constexpr bool kRegMatchLen = HC_LZ4_REG_MATCH_LEN != 0;
+
 
 __device__ __forceinline__ uint32_t hash_sum(uint32_t key)
 {
@@ -169,13 +162,12 @@ __device__ __forceinline__ void insert_window(
 // (reference lengthOfMatch :592-617), compared 4 bytes per lane per step.
 template <int S>
 __device__ __forceinline__ uint32_t match_length(
-    cgptr in, uint32_t prev, uint32_t pos, uint32_t limit, int lane,
-    uint32_t start_bytes = 0)
+    cgptr in, uint32_t prev, uint32_t pos, uint32_t limit, int lane)
 {
   cgptr a = in + (size_t)prev * S;
   cgptr b = in + (size_t)pos * S;
   const uint32_t limit_bytes = limit * S;
-  for (uint32_t j = start_bytes; j < limit_bytes; j += 4 * kWave) {
+  for (uint32_t j = 0; j < limit_bytes; j += 4 * kWave) {
     const uint32_t i = j + 4u * (uint32_t)lane;
     uint32_t diff_at = 4; // byte index of first difference inside my dword
     if (i + 4 <= limit_bytes) {
@@ -248,6 +240,9 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
   // match-less iteration)
   uint32_t next = 0;
   bool have_next = false;
+  // highest element with 4 readable bytes; windows exist only while
+  // d + LVM < L, so the clamp below is only ever used with L > LVM
+  const uint32_t last_word = L > LVM ? L - LVM - 1 : 0;
 
   while (d < L) {
     const uint32_t token_start = d;
@@ -259,26 +254,29 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
         d = L;
         break;
       }
-      int nv = NVMAX;
-      if ((int)(L - d - LVM) < nv)
-        nv = (int)(L - d - LVM);
+      const int nv = min(NVMAX, (int)(L - d - LVM)); // >= 1
+      const uint64_t vmask = lanes_below<NVMAX>(nv);
       const bool valid = lane < nv;
-
-      // window word of lane t = the 4 bytes at element d+t (reference
-      // :848-854; for every lane < nv none of them is masked)
-      // (loads are unconditional with a clamped, always readable index so
-      // that the compiler can count them: a load under a branch would force
-      // s_waitcnt vmcnt(0) at the first use of ANY older load)
-      const uint32_t last_word = L - LVM - 1; // highest element with 4 readable bytes
-      if (!have_next)
-        next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
-      const uint32_t hpos = hash_sum(next) & hmask;
       const uint32_t pos = d + (uint32_t)lane;
 
+      // window word of lane t = the 4 bytes at element d+t (reference
+      // :848-854; for every lane < nv none of them is masked).  Loads are
+      // unconditional with a clamped, always readable index so that the
+      // compiler can count them: a load under a branch would force
+      // s_waitcnt vmcnt(0) at the first use of ANY older load.
+      if (!have_next)
+        next = load_u32_any(in + (size_t)min(pos, last_word) * S);
+      const uint32_t hpos = hash_sum(next) & hmask;
+
       // (B) candidate from earlier windows (reference isValidHash :634-663,
-      // convertIdx :619-632): table read now, 4-byte verify load issued as
-      // early as possible.
-      const uint32_t h_old = valid ? (uint32_t)table[hpos] : kNullOffset;
+      // convertIdx :619-632).  The table read needs no mask: hpos is always
+      // inside the table.
+      const uint32_t h_old = table[hpos];
+      // (A) in-window duplicates, step 1: my slot and "I am a valid lane" go
+      // to the mirrored lane (see below); issued together with the table read
+      const uint32_t pr = (uint32_t)__builtin_amdgcn_ds_bpermute(
+          rev_addr4, (int)(hpos | (valid ? 0x80000000u : 0u)));
+
       uint32_t cand = (pos & ~0xFFFFu) + h_old;
       if (cand >= pos)
         cand -= 65536u;
@@ -292,29 +290,15 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
 #ifdef HC_ABL_NO_VERIFY
       const bool probe = false;
 #else
-      const bool probe = h_old != kNullOffset && dist * S <= 65535u && dist <= 65535u;
+      const bool probe = valid && h_old != kNullOffset && dist * S <= 65535u;
 #endif
-      // 16 bytes at the candidate: dword 0 verifies the hash hit, dwords 1..3
-      // let the common short match be measured from registers (below) instead
-      // of a second trip to memory.  16 bytes may not be readable for a
-      // candidate in the last bytes of the chunk (S < 4 only): such a window
-      // takes the 4-byte load and the generic match-length path.
-      const uint32_t probe_byte = (probe ? cand : min(pos, last_word)) * S;
-      const bool wide_ok = kRegMatchLen && wave_ballot(probe_byte + 16u > len) == 0;
-      u32x4 cw;
-      if (wide_ok) {
-        cw = load_u128_any(in + probe_byte);
-      } else {
-        cw.x = load_u32_any(in + probe_byte);
-        cw.y = cw.z = cw.w = 0;
-      }
-      const uint32_t cand_word = cw.x;
-
-      // Speculative load of the next window (d + nv): issued AFTER the verify
-      // load so that waiting for the verify (in-order vmcnt) does not wait
-      // for it.  Used only if this window ends without a match.
+      // 4-byte verify load, then the speculative load of the next window
+      // (d + nv): the latter is issued AFTER the verify so that waiting for
+      // the verify (in-order vmcnt) does not wait for it
+      const uint32_t cand_word
+          = load_u32_any(in + (size_t)(probe ? cand : min(pos, last_word)) * S);
       const uint32_t next_pf = load_u32_any(
-          in + (size_t)min(d + (uint32_t)nv + (uint32_t)lane, last_word) * S);
+          in + (size_t)min(pos + (uint32_t)nv, last_word) * S);
 
       // (A) in-window duplicates: lowest lane holding my word, found through
       // the hash table itself (no scratch LDS).  Every valid lane posts its
@@ -325,109 +309,59 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
       // different words share the slot and the lane is settled by the exact
       // fallback below.  The slots are then put back (h_old) before the real
       // insert.
-      {
-        const uint32_t packed = hpos | (valid ? 0x80000000u : 0u);
-        const uint32_t pr = (uint32_t)__builtin_amdgcn_ds_bpermute(rev_addr4, (int)packed);
-        lds_lane_exchange_fence();
-        if (pr & 0x80000000u)
-          table[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
-        lds_lane_exchange_fence();
-      }
-      const uint32_t w = valid ? (uint32_t)table[hpos] : (uint32_t)lane;
+      lds_lane_exchange_fence();
+      if (pr & 0x80000000u)
+        table[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
+      lds_lane_exchange_fence();
+      const uint32_t w_raw = table[hpos];
       lds_lane_exchange_fence();
       if (valid)
         table[hpos] = (uint16_t)h_old;
       lds_lane_exchange_fence();
+      const uint32_t w = valid ? w_raw : (uint32_t)lane;
       const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)next);
-      // masks are combined as scalars: each ballot is one v_cmp
-      const uint64_t vmask = low_lanes_mask(nv);
-      const uint64_t eqmask = wave_ballot(nw == next) & vmask;
+      // masks are combined as scalars: each ballot is one v_cmp.  (An
+      // invalid lane has w == lane, so it can be neither dup nor unresolved.)
+      const uint64_t eqmask = wave_ballot(nw == next);
       const uint64_t dupmask = eqmask & wave_ballot(w != (uint32_t)lane);
       const uint64_t unres = vmask & ~eqmask;
 
-      int f = nv;         // first lane with an equal lower lane
-      uint32_t mlane = 0; // that lower lane
-      if (dupmask) {
-        f = __builtin_ctzll(dupmask);
-        mlane = read_lane(w, f);
+      // first lane with an equal lower lane (nv if none) and that lower lane
+      int f = dupmask ? __builtin_ctzll(dupmask) : nv;
+      uint32_t mlane = read_lane(w, f & 63);
+      uint64_t U = unres & lanes_below<NVMAX>(f);
+      if (__builtin_expect(U != 0, 0)) {
+        do {
+          const int u = __builtin_ctzll(U);
+          U &= U - 1;
+          const uint32_t v = read_lane(next, u);
+          const uint64_t m = wave_ballot(next == v) & vmask;
+          const int lo = __builtin_ctzll(m);
+          if (lo != u) {
+            f = u;
+            mlane = (uint32_t)lo;
+            break;
+          }
+        } while (U);
       }
-      uint64_t U = unres & low_lanes_mask(f);
-      while (U) {
-        const int u = __builtin_ctzll(U);
-        U &= U - 1;
-        const uint32_t v = read_lane(next, u);
-        const uint64_t m = wave_ballot(next == v) & vmask;
-        const int lo = __builtin_ctzll(m);
-        if (lo != u) {
-          f = u;
-          mlane = (uint32_t)lo;
-          break;
-        }
-      }
-      uint32_t match_location = (f < nv) ? d + mlane : L;
-
       // earliest lane (< f) with a verified table candidate wins
       // (reference :896-923)
       const uint64_t tmask
-          = wave_ballot(cand_word == next) & wave_ballot(probe) & low_lanes_mask(f);
-      if (tmask) {
+          = wave_ballot(cand_word == next) & wave_ballot(probe) & lanes_below<NVMAX>(f);
+      const bool in_window = f < nv;
+      if (tmask)
         f = __builtin_ctzll(tmask);
-        match_location = read_lane(cand, f);
-      }
+      const uint32_t tcand = read_lane(cand, f & 63);
 
-      if (match_location != L) {
+      if (tmask != 0 || in_window) {
         // reference :925-956
+        const uint32_t match_location = tmask ? tcand : d + mlane;
         insert_window(table, hpos, d, f, lane, perm);
         const uint32_t mpos = d + (uint32_t)f;
         const uint32_t off_elems = (mpos - match_location) & 0xFFFFu;
         const uint32_t lit = mpos - token_start;
-        const uint32_t limit = L - mpos - MEL;
-
-        // ---- match length (reference lengthOfMatch :592-617).  Up to 16
-        // bytes are compared in registers: the window side are the words of
-        // lanes f, f+4/S, ...; the other side is the winner's 16 candidate
-        // bytes (table match) or the words of lanes mlane, mlane+4/S, ...
-        // (in-window match).  Only a longer match goes back to memory.
-        uint32_t ml;
-        {
-          constexpr int LSTEP = 4 / S;                 // lanes per dword
-          const bool from_table = tmask != 0;
-          const int src_lane = from_table ? f : (int)(match_location - d);
-          const uint32_t limit_bytes = limit * S;
-          uint32_t known = 0;                           // equal bytes so far (multiple of 4)
-          bool done = false;
-          uint32_t mb = 0;
-#pragma unroll
-          for (int k = 0; k < (kRegMatchLen ? 4 : 0) && !done; ++k) {
-            const int wl = f + k * LSTEP;
-            // window word k must be real data: its lane exists and was not clamped
-            if (wl > 63 || d + (uint32_t)wl > last_word || (from_table && !wide_ok && k > 0)) {
-              break;
-            }
-            const uint32_t ww = read_lane(next, wl);
-            uint32_t cc;
-            if (from_table) {
-              cc = k == 0 ? read_lane(cw.x, f) : k == 1 ? read_lane(cw.y, f) : k == 2 ? read_lane(cw.z, f) : read_lane(cw.w, f);
-            } else {
-              cc = read_lane(next, src_lane + k * LSTEP); // src_lane < f: same validity
-            }
-            const uint32_t x = ww ^ cc;
-            if (x) {
-              mb = known + ((uint32_t)__builtin_ctz(x) >> 3);
-              done = true;
-            } else {
-              known += 4;
-              if (known >= limit_bytes) {
-                mb = limit_bytes;
-                done = true;
-              }
-            }
-          }
-          if (done)
-            ml = min(mb, limit_bytes) / S;
-          else
-            ml = match_length<S>(in, match_location, mpos, limit, lane, known);
-        }
+        const uint32_t ml
+            = match_length<S>(in, match_location, mpos, L - mpos - MEL, lane);
 
         // ---- emit (reference writeSequenceData :665-715).  Fast path: the
         // whole sequence started in this window and is short, so its literal
@@ -440,15 +374,15 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
           const uint32_t i = (uint32_t)lane;
           const uint32_t li = i - 1;                       // literal byte index
           const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((li / S) * 4u), (int)next);
-          uint32_t b = (src >> (8u * (li % S))) & 0xFFu;
+          uint32_t bt = (src >> (8u * (li % S))) & 0xFFu;
           if (i == 0)
-            b = (lit_bytes << 4) | ((match_bytes - 4u) & 0x0Fu);
+            bt = (lit_bytes << 4) | ((match_bytes - 4u) & 0x0Fu);
           else if (i == lit_bytes + 1)
-            b = offset_bytes & 0xFFu;
+            bt = offset_bytes & 0xFFu;
           else if (i == lit_bytes + 2)
-            b = offset_bytes >> 8;
+            bt = offset_bytes >> 8;
           if (i < lit_bytes + 3)
-            out[c + i] = (uint8_t)b;
+            out[c + i] = (uint8_t)bt;
           c += lit_bytes + 3;
         } else {
           c = write_sequence(out, c, in + (size_t)token_start * S, lit_bytes,

@@ -66,6 +66,16 @@ __device__ __forceinline__ uint64_t wave_ballot(bool p)
   return __builtin_amdgcn_ballot_w64(p);
 }
 
+// lanes [0, n), n in [0, MAXN]; the n == 64 case is only compiled in when the
+// caller can actually pass it
+template <int MAXN>
+__device__ __forceinline__ uint64_t lanes_below(int n)
+{
+  if (MAXN >= 64)
+    return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+  return (1ull << n) - 1ull;
+}
+
 __device__ __forceinline__ uint64_t low_lanes_mask(int n) // lanes [0, n)
 {
   return n >= 64 ? ~0ull : ((1ull << n) - 1ull);

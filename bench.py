@@ -23,7 +23,6 @@ import importlib
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -109,56 +108,88 @@ def time_phases(job: Lz4Job, steps: int):
     return tc, td
 
 
-def cpu_liblz4_baseline(sample: np.ndarray, budget_s: float = 12.0):
-    """System liblz4 round trip on the host cores (BASELINE.json configs[0])."""
-    try:
-        lz4 = ctypes.CDLL("liblz4.so.1")
-    except OSError:
-        return None
-    lz4.LZ4_compressBound.argtypes = [ctypes.c_int]
-    lz4.LZ4_compress_default.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-    lz4.LZ4_decompress_safe.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+def cpu_liblz4_baseline(sample: np.ndarray, reps: int = 3):
+    """System liblz4 round trip on the host cores (BASELINE.json configs[0]):
+    oracle/cpu_baseline.c -- pthreads, static contiguous partition, best of
+    `reps`.  Falls back to the scalar C restatement when liblz4 is absent."""
+    from oracle import oracle as O
+    L = O.lib()
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     n = sample.size // CHUNK
-    bound = lz4.LZ4_compressBound(CHUNK)
-    comp = np.empty(n * bound, dtype=np.uint8)
-    out = np.empty(n * CHUNK, dtype=np.uint8)
-    csz = np.zeros(n, dtype=np.int64)
-    sp, cp, op = sample.ctypes.data, comp.ctypes.data, out.ctypes.data
-
-    def work(lo, hi, phase):
-        for i in range(lo, hi):
-            if phase == 0:
-                csz[i] = lz4.LZ4_compress_default(sp + i * CHUNK, cp + i * bound, CHUNK, bound)
-            else:
-                lz4.LZ4_decompress_safe(cp + i * bound, op + i * CHUNK, int(csz[i]), CHUNK)
-
-    def run(phase):
-        per = (n + cores - 1) // cores
-        ts = [threading.Thread(target=work, args=(k * per, min(n, (k + 1) * per), phase)) for k in range(cores)]
-        t0 = time.perf_counter()
-        [t.start() for t in ts]
-        [t.join() for t in ts]
-        return time.perf_counter() - t0
-
-    best_c = best_d = 1e30
-    t_start = time.perf_counter()
-    reps = 0
-    while reps < 3 and time.perf_counter() - t_start < budget_s:
-        best_c = min(best_c, run(0))
-        best_d = min(best_d, run(1))
-        reps += 1
-    assert bytes(out[:CHUNK]) == bytes(sample[:CHUNK])
+    tc, td, ct = ctypes.c_double(), ctypes.c_double(), ctypes.c_size_t()
+    L.cpu_liblz4_roundtrip.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(ctypes.c_size_t)]
+    rc = L.cpu_liblz4_roundtrip(sample.ctypes.data, n, CHUNK, cores, reps, ctypes.byref(tc), ctypes.byref(td),
+                                ctypes.byref(ct))
     total = n * CHUNK
-    return {
-        "value": total / (best_c + best_d) / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
-        "sample": f"system liblz4 (LZ4_compress_default + LZ4_decompress_safe), {n} x 64KiB chunks of the same data, "
-                  f"{cores} threads, best of {reps}; compress {total / best_c / 1e9:.2f} GB/s, "
-                  f"decompress {total / best_d / 1e9:.2f} GB/s, ratio {total / max(int(csz.sum()), 1):.3f}",
-    }
+    if rc == 0:
+        return {
+            "value": total / (tc.value + td.value) / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"system liblz4 (LZ4_compress_default + LZ4_decompress_safe via oracle/cpu_baseline.c), "
+                      f"{n} x 64KiB chunks of the same data, {cores} pthreads, best of {reps}; "
+                      f"compress {total / tc.value / 1e9:.2f} GB/s, decompress {total / td.value / 1e9:.2f} GB/s, "
+                      f"ratio {total / max(ct.value, 1):.3f}",
+        }
+    # no liblz4 on this box: time the C restatement (scalar, 1 core)
+    t1 = time.perf_counter()
+    kk = min(64, n)
+    for i in range(kk):
+        O.lz4_compress(bytes(sample[i * CHUNK:(i + 1) * CHUNK]), 1, CHUNK)
+    dt = time.perf_counter() - t1
+    return {"value": kk * CHUNK / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/lz4_oracle.c compress only, {kk} chunks (liblz4 unavailable, rc={rc})"}
+
+
+# ---- multi-GPU plumbing (chunks shard with no data-path collective) ----------
+
+def shard_seed(base_seed: int, rank: int) -> int:
+    """Every rank owns its own slice of the chunk list: same size, own seed."""
+    return base_seed + rank
+
+
+def aggregate_throughput(local_wall_s: float, local_bytes: int, steps: int, dist_mod=None, device=None):
+    """Whole-job GB/s: all ranks' bytes over the slowest rank's time."""
+    wall, total = local_wall_s, float(local_bytes)
+    if dist_mod is not None and dist_mod.is_initialized() and dist_mod.get_world_size() > 1:
+        t = torch.tensor([local_wall_s], dtype=torch.float64, device=device)
+        b = torch.tensor([float(local_bytes)], dtype=torch.float64, device=device)
+        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+        dist_mod.all_reduce(b, op=dist_mod.ReduceOp.SUM)
+        wall, total = float(t.item()), float(b.item())
+    return total / (wall / steps) / 1e9, wall
+
+
+def measure_variant(hc, lib, dev, dist_name: str, dtype_name: str, chunks: int, seed: int):
+    """Compress / decompress ms of one (distribution, data_type) row."""
+    data = gen_data(dist_name, chunks, dev, seed)
+    dtype = hc.hipcompType.CHAR if dtype_name == "char" else hc.hipcompType.INT
+    job = Lz4Job(hc, lib, data, dtype)
+    job.compress(); job.decompress(); torch.cuda.synchronize()
+    job.verify()
+    tc, td = time_phases(job, 2)
+    nb, cb = job.n * CHUNK, int(job.comp.sizes.sum().item())
+    return {"distribution": dist_name, "data_type": dtype_name.upper(), "chunks": chunks, "ratio": nb / max(cb, 1),
+            "compress_GBps": nb / (min(tc) * 1e-3) / 1e9, "decompress_GBps": nb / (min(td) * 1e-3) / 1e9,
+            "roundtrip_GBps": nb / ((min(tc) + min(td)) * 1e-3) / 1e9,
+            "hbm_frac_compress": (nb + cb) / (min(tc) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
+def pmc_traffic(args):
+    """HBM bytes per compress launch from the committed rocprofv3 PMC passes
+    (profiles/lz4_hbm_traffic.json: FETCH_SIZE doubled as the gfx950 note in
+    MI355X_MICROARCH.md prescribes, + WRITE_SIZE), or None when no pass exists
+    for this workload."""
+    path = os.path.join(ROOT, "profiles", "lz4_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    key = f"{args.dist}/{args.dtype}/{args.chunks}"
+    return table.get(key, {}).get("traffic_bytes_per_launch")
 
 
 def main():
@@ -171,7 +202,9 @@ def main():
     ap.add_argument("--dtype", default="char", choices=["char", "int"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--ref", action="store_true", help="also time the reference build (oracle/_ref) on the same buffers")
-    ap.add_argument("--cpu-sample-chunks", type=int, default=8192)
+    ap.add_argument("--cpu-sample-chunks", type=int, default=16384)
+    ap.add_argument("--no-variants", dest="variants", action="store_false",
+                    help="skip the extra (distribution, data_type) rows")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,7 +222,7 @@ def main():
     lib = hc.default_library()
     dtype = hc.hipcompType.CHAR if args.dtype == "char" else hc.hipcompType.INT
 
-    data = gen_data(args.dist, args.chunks, dev, seed=0x5EED0002 + rank)
+    data = gen_data(args.dist, args.chunks, dev, seed=shard_seed(0x5EED0002, rank))
     job = Lz4Job(hc, lib, data, dtype)
 
     def barrier():
@@ -208,16 +241,11 @@ def main():
     t0 = time.perf_counter()
     tc, td = time_phases(job, args.steps)
     barrier()
-    wall = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-
+    wall_local = time.perf_counter() - t0
     n_bytes = job.n * CHUNK
     c_bytes = int(job.comp.sizes.sum().item())
+    value, wall = aggregate_throughput(wall_local, n_bytes, args.steps, dist if dist_on else None, dev)
     ms_step = wall / args.steps * 1e3
-    value = world * n_bytes / (wall / args.steps) / 1e9
 
     if rank == 0:
         tc_avg, td_avg = sum(tc) / len(tc), sum(td) / len(td)
@@ -240,7 +268,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "lz4_compress_kernel",
                 "achieved": algo / (tc_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": algo / (tc_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "frac": algo / (tc_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
                 "algorithmic_bytes_per_launch": algo,
                 "decompress_achieved": algo / (td_avg * 1e-3) / 1e9,
             },
@@ -259,21 +287,12 @@ def main():
                     "compressed_sizes_identical": same,
                 }
                 del rjob
-        if not args.no_cpu:
+        if args.variants and world == 1:
+            res["variants"] = [measure_variant(hc, lib, dev, dn, tn, min(args.chunks, 20000), 0x5EED0003 + i)
+                               for i, (dn, tn) in enumerate((("uniform", "int"), ("harness", "char"), ("runs", "char")))]
+        if not args.no_cpu and world == 1:  # reported at N=1 only
             k = min(args.cpu_sample_chunks, job.n)
-            sample = data[: k * CHUNK].cpu().numpy()
-            cb = cpu_liblz4_baseline(sample)
-            if cb is None:
-                # no liblz4 on this box: time the C restatement (scalar, 1 core)
-                from oracle import oracle as O
-                t1 = time.perf_counter()
-                kk = min(64, k)
-                for i in range(kk):
-                    O.lz4_compress(bytes(sample[i * CHUNK:(i + 1) * CHUNK]), 1, CHUNK)
-                dt = time.perf_counter() - t1
-                cb = {"value": kk * CHUNK / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
-                      "sample": f"oracle/lz4_oracle.c compress only, {kk} chunks (liblz4 unavailable)"}
-            res["cpu_baseline"] = cb
+            res["cpu_baseline"] = cpu_liblz4_baseline(data[: k * CHUNK].cpu().numpy())
         print(json.dumps(res))
     if dist_on:
         dist.destroy_process_group()

@@ -422,7 +422,7 @@ __device__ __forceinline__ bool read_lsic(
   while (b == 0xff) {
     if (c >= end)
       return false;
-    b = comp[c++];
+    b = uniform((uint32_t)comp[c++]);
     num += b;
   }
   return true;
@@ -439,19 +439,20 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
     hipcompStatus_t* __restrict__ statuses)
 {
   const int lane = lane_id();
+  // everything that steers the parse is wave-uniform: say so (see uniform())
   const size_t chunk
-      = (size_t)blockIdx.x * kDecompWavesPerBlock + (threadIdx.x >> 6);
+      = (size_t)blockIdx.x * kDecompWavesPerBlock + uniform((uint32_t)(threadIdx.x >> 6));
   if (chunk >= batch)
     return;
-  cgptr comp = to_global(comp_ptrs[chunk]);
-  const uint32_t end = (uint32_t)comp_bytes[chunk];
-  const uint32_t cap = WRITE_OUT ? (uint32_t)out_caps[chunk] : 0xFFFFFFFFu;
-  gptr out = WRITE_OUT ? to_global(out_ptrs[chunk]) : nullptr;
+  cgptr comp = to_global(uniform_ptr(comp_ptrs[chunk]));
+  const uint32_t end = uniform((uint32_t)comp_bytes[chunk]);
+  const uint32_t cap = WRITE_OUT ? uniform((uint32_t)out_caps[chunk]) : 0xFFFFFFFFu;
+  gptr out = WRITE_OUT ? to_global(uniform_ptr(out_ptrs[chunk])) : nullptr;
 
   uint32_t c = 0, d = 0;
   bool corrupt = false;
   while (c < end) {
-    const uint32_t tok = comp[c++];
+    const uint32_t tok = uniform((uint32_t)comp[c++]);
     uint32_t lit = tok >> 4;
     if (lit == 15 && !read_lsic(comp, c, end, lit)) {
       corrupt = true;
@@ -461,8 +462,15 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
       corrupt = true;
       break;
     }
-    if (WRITE_OUT)
-      wave_copy(out + d, comp + c, lit, lane);
+    if (WRITE_OUT && lit) {
+      // short runs (the common case on compressible data): one byte per lane
+      if (lit <= kWave) {
+        if ((uint32_t)lane < lit)
+          out[d + lane] = comp[c + lane];
+      } else {
+        wave_copy(out + d, comp + c, lit, lane);
+      }
+    }
     c += lit;
     d += lit;
     if (c < end) { // reference :1035
@@ -470,7 +478,8 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
         corrupt = true;
         break;
       }
-      const uint32_t offset = (uint32_t)comp[c] | ((uint32_t)comp[c + 1] << 8);
+      const uint32_t lit_end = c; // the literal run ends where the offset field starts
+      const uint32_t offset = uniform((uint32_t)comp[c] | ((uint32_t)comp[c + 1] << 8));
       c += 2;
       uint32_t ml = 4 + (tok & 0x0fu);
       if ((tok & 0x0fu) == 15 && !read_lsic(comp, c, end, ml)) {
@@ -484,11 +493,22 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
       if (WRITE_OUT) {
         // Earlier stores of this wave to out[] are ordered before these
         // loads (one wave, in-order vector memory, one L1).
-        cgptr src = out + d - offset;
+        // Source of the match: normally the already written output.  When the
+        // match reaches back only into the literal run of this same sequence
+        // (offset <= lit) the very same bytes sit in the compressed stream
+        // just before the offset field -- reading them there avoids a
+        // store -> load round trip through memory on out[] (reference
+        // :1062-1070 does the same from its LDS staging buffer).
+        cgptr src = offset <= lit ? comp + (lit_end - offset) : static_cast<cgptr>(out + d - offset);
         gptr dst = out + d;
         if (offset >= ml) {
-          for (uint32_t i = (uint32_t)lane; i < ml; i += kWave)
-            dst[i] = src[i];
+          if (ml <= kWave) {
+            if ((uint32_t)lane < ml)
+              dst[lane] = src[lane];
+          } else {
+            // long match, source and destination do not overlap (offset >= ml)
+            wave_copy(dst, src, ml, lane);
+          }
         } else {
           for (uint32_t i = (uint32_t)lane; i < ml; i += kWave)
             dst[i] = src[i % offset];

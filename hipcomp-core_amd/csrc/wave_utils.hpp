@@ -43,6 +43,26 @@ __device__ __forceinline__ int lane_id()
   return (int)(threadIdx.x & (kWave - 1));
 }
 
+// Tell the compiler a value is the same in every lane (it came from a load
+// at a wave-uniform address, which lands in a VGPR): the value moves to an
+// SGPR and everything computed from it -- loop bounds, branch conditions,
+// addresses -- becomes scalar.  Without this, loops steered by loaded values
+// are compiled as DIVERGENT control flow: every `if` turns into exec-mask
+// save/restore sequences on the CU's single scalar ALU.
+__device__ __forceinline__ uint32_t uniform(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint64_t uniform(uint64_t v)
+{
+  return (uint64_t)uniform((uint32_t)v) | ((uint64_t)uniform((uint32_t)(v >> 32)) << 32);
+}
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p)
+{
+  return reinterpret_cast<T*>(uniform((uint64_t)reinterpret_cast<uintptr_t>(p)));
+}
+
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane)
 {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);

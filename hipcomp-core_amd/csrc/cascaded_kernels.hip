@@ -154,6 +154,13 @@ __device__ __forceinline__ uint32_t wave_write_array(
     }
     mn = wave_min(mn);
     mx = wave_max(mx);
+    if (ES > 4) {
+      mn = (SET)uniform((uint64_t)mn);
+      mx = (SET)uniform((uint64_t)mx);
+    } else {
+      mn = (SET)uniform((uint32_t)(int32_t)mn);
+      mx = (SET)uniform((uint32_t)(int32_t)mx);
+    }
   }
   uint32_t bw;
   if (ES > 4) {
@@ -219,7 +226,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
   typedef typename UIntOf<S>::type UT;
   __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * wave_lds_bytes<S>()];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  // everything that steers the layers is wave-uniform: say so (see uniform())
+  const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
   const size_t part = (size_t)blockIdx.x * kWavesPerBlock + wave;
   if (part >= batch)
     return;
@@ -229,9 +237,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
   uint16_t* cnts = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes());
   uint32_t* meta = reinterpret_cast<uint32_t*>(my + 2 * elem_buf_bytes() + (kChunkBytes / S) * 2);
 
-  cgptr in = to_global(in_ptrs[part]);
-  const size_t in_bytes64 = in_bytes_arr[part];
-  gptr out = to_global(out_ptrs[part]);
+  cgptr in = to_global(uniform_ptr(in_ptrs[part]));
+  const size_t in_bytes64 = uniform((uint64_t)in_bytes_arr[part]);
+  gptr out = to_global(uniform_ptr(out_ptrs[part]));
   if (in == nullptr || in_bytes64 == 0) { // reference :856-860
     if (lane == 0)
       out_bytes_arr[part] = 0;
@@ -373,10 +381,10 @@ __device__ __forceinline__ int unpack_array(
     return -1;
   ET fr;
   if (ES > 4)
-    fr = (ET)((uint64_t)src[0] | ((uint64_t)src[1] << 32));
+    fr = (ET)uniform((uint64_t)src[0] | ((uint64_t)src[1] << 32));
   else
-    fr = (ET)src[0];
-  const uint32_t word = src[ES > 4 ? 2 : 1];
+    fr = (ET)uniform((uint32_t)src[0]);
+  const uint32_t word = uniform((uint32_t)src[ES > 4 ? 2 : 1]);
   const uint32_t bw = word >> 16;
   const uint32_t n = word & 0xFFFFu;
   if (n == 0)
@@ -436,12 +444,12 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
   const size_t part = blockIdx.x;
   if (part >= batch)
     return;
-  cgptr comp = to_global(comp_ptrs[part]);
-  const size_t comp_bytes64 = comp_bytes_arr[part];
+  cgptr comp = to_global(uniform_ptr(comp_ptrs[part]));
+  const size_t comp_bytes64 = uniform((uint64_t)comp_bytes_arr[part]);
   const bool bad_header = comp == nullptr || comp_bytes64 < kPartMeta;
   uint32_t type = 0xFFu;
   if (!bad_header)
-    type = comp[3];
+    type = uniform((uint32_t)comp[3]);
   // Each width has its own launch; a partition is handled by the launch that
   // matches ITS type byte (the reference dispatches on partition 0 only).
   // Undecodable headers are reported by the 1-byte launch.
@@ -461,11 +469,12 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
     return;
   }
   const uint32_t comp_bytes = (uint32_t)comp_bytes64;
-  const int R = comp[0], D = comp[1], bp = comp[2];
-  const uint32_t ub = *reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + 4);
+  const uint32_t hdr = uniform(*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp));
+  const int R = (int)(hdr & 0xFFu), D = (int)((hdr >> 8) & 0xFFu), bp = (int)((hdr >> 16) & 0xFFu);
+  const uint32_t ub = uniform(*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + 4));
   const uint32_t N = ub / S;
-  gptr out = to_global(out_ptrs[part]);
-  if (out_caps[part] < (size_t)N * S) { // reference :1214-1223
+  gptr out = to_global(uniform_ptr(out_ptrs[part]));
+  if (uniform((uint64_t)out_caps[part]) < (size_t)N * S) { // reference :1214-1223
     finish(false, 0);
     return;
   }
@@ -519,7 +528,7 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       stage[lane + k * kWave] = pf[k];
-    const uint32_t csz = meta[0];
+    const uint32_t csz = uniform(meta[0]);
     if (csz == 0) {
       ok = false;
       break;
@@ -532,14 +541,14 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
     {
       uint32_t o = 0;
       for (int i = 0; i < R; ++i) {
-        const uint32_t sz = meta[i + 1];
+        const uint32_t sz = uniform(meta[i + 1]);
         o = ru(o + sz, (i == R - 1) ? (S > 4 ? (uint32_t)S : 4u) : 4u);
       }
       offs_final = o;
     }
     UT* x = bufA;
     UT* y = bufB;
-    int n = wave_read_array<UT>(comp, end_w, pos, msz + offs_final, meta[1 + R], bp, stage, x, CE, lane);
+    int n = wave_read_array<UT>(comp, end_w, pos, msz + offs_final, uniform(meta[1 + R]), bp, stage, x, CE, lane);
     if (n < 0) {
       ok = false;
       break;
@@ -585,8 +594,8 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
       if (l < R) { // reference block_rle_decompress :255-305
         uint32_t o = 0;
         for (int i = 0; i < l; ++i)
-          o = ru(o + meta[i + 1], 4u);
-        const int m = wave_read_array<uint16_t>(comp, end_w, pos, msz + o, meta[l + 1], bp, stage, cnts, CE, lane);
+          o = ru(o + uniform(meta[i + 1]), 4u);
+        const int m = wave_read_array<uint16_t>(comp, end_w, pos, msz + o, uniform(meta[l + 1]), bp, stage, cnts, CE, lane);
         if (m < 0 || m != n) {
           ok = false;
           break;

@@ -56,9 +56,9 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
 
   const int lane = (int)threadIdx.x;
   const size_t chunk = blockIdx.x;
-  cgptr __restrict__ src = to_global(in_ptrs[chunk]);
-  const uint32_t len = (uint32_t)in_bytes[chunk];
-  gptr __restrict__ dst = to_global(out_ptrs[chunk]);
+  cgptr __restrict__ src = to_global(uniform_ptr(in_ptrs[chunk]));
+  const uint32_t len = uniform((uint32_t)in_bytes[chunk]);
+  gptr __restrict__ dst = to_global(uniform_ptr(out_ptrs[chunk]));
 
   // varint of the uncompressed length (reference :316-322)
   uint32_t c = 0;
@@ -279,12 +279,13 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
     hipcompStatus_t* __restrict__ statuses)
 {
   const int lane = lane_id();
-  const size_t chunk = (size_t)blockIdx.x * kDecompWavesPerBlock + (threadIdx.x >> 6);
+  // everything that steers the parse is wave-uniform: say so (see uniform())
+  const size_t chunk = (size_t)blockIdx.x * kDecompWavesPerBlock + uniform((uint32_t)(threadIdx.x >> 6));
   if (chunk >= batch)
     return;
-  cgptr comp = to_global(comp_ptrs[chunk]);
-  const uint32_t end = (uint32_t)comp_bytes[chunk];
-  gptr out = to_global(out_ptrs[chunk]);
+  cgptr comp = to_global(uniform_ptr(comp_ptrs[chunk]));
+  const uint32_t end = uniform((uint32_t)comp_bytes[chunk]);
+  gptr out = to_global(uniform_ptr(out_ptrs[chunk]));
 
   uint32_t usize = 0, bytes_left = 0;
   bool error = false;
@@ -294,7 +295,9 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
     uint32_t cur = 0;
     if (!read_preamble(comp, end, cur, usize))
       error = true;
-    size_t cap = out_caps[chunk];
+    usize = uniform(usize);
+    cur = uniform(cur);
+    size_t cap = uniform((uint64_t)out_caps[chunk]);
     if (cap == 0)
       cap = usize; // reference decompression.hiph:148-149
     if ((cur >= end && usize != 0) || usize > cap)
@@ -307,25 +310,26 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
       while (bytes_left > 0) {
         if (cur >= end)
           break;
-        const uint32_t b0 = comp[cur];
+        // tag byte plus the four bytes behind it (clamped to the stream), uniform
+        const uint32_t b0 = uniform((uint32_t)comp[cur]);
         uint32_t blen, offset;
         if (b0 & 3u) {
           if (!(b0 & 2u)) { // xxxxxx01.oooooooo
             if (end - cur < 2)
               break;
-            offset = ((b0 & 0xe0u) << 3) | comp[cur + 1];
+            offset = ((b0 & 0xe0u) << 3) | uniform((uint32_t)comp[cur + 1]);
             blen = ((b0 >> 2) & 7u) + 4u;
             cur += 2;
           } else if (b0 & 1u) { // 4-byte offset
             if (end - cur < 5)
               break;
-            offset = load_u32_any(comp + cur + 1);
+            offset = uniform(load_u32_any(comp + cur + 1));
             blen = (b0 >> 2) + 1u;
             cur += 5;
           } else { // 2-byte offset
             if (end - cur < 3)
               break;
-            offset = (uint32_t)comp[cur + 1] | ((uint32_t)comp[cur + 2] << 8);
+            offset = uniform((uint32_t)comp[cur + 1] | ((uint32_t)comp[cur + 2] << 8));
             blen = (b0 >> 2) + 1u;
             cur += 3;
           }
@@ -347,13 +351,18 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
               break;
             blen = 0;
             for (uint32_t i = 0; i < nb; ++i)
-              blen |= (uint32_t)comp[cur + i] << (8 * i);
+              blen |= uniform((uint32_t)comp[cur + i]) << (8 * i);
             cur += nb;
           }
           blen += 1;
           if (blen == 0 || bytes_left < blen || end - cur < blen)
             break;
-          wave_copy(out + dst_pos, comp + cur, blen, lane);
+          if (blen <= kWave) {
+            if ((uint32_t)lane < blen)
+              out[dst_pos + lane] = comp[cur + lane];
+          } else {
+            wave_copy(out + dst_pos, comp + cur, blen, lane);
+          }
           cur += blen;
         }
         dst_pos += blen;

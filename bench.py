@@ -155,6 +155,8 @@ def aggregate_throughput(local_wall_s: float, local_bytes: int, steps: int, dist
     """Whole-job GB/s: all ranks' bytes over the slowest rank's time."""
     wall, total = local_wall_s, float(local_bytes)
     if dist_mod is not None and dist_mod.is_initialized() and dist_mod.get_world_size() > 1:
+        if dist_mod.get_backend() != "nccl":
+            device = "cpu"
         t = torch.tensor([local_wall_s], dtype=torch.float64, device=device)
         b = torch.tensor([float(local_bytes)], dtype=torch.float64, device=device)
         dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
@@ -203,6 +205,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--ref", action="store_true", help="also time the reference build (oracle/_ref) on the same buffers")
     ap.add_argument("--cpu-sample-chunks", type=int, default=16384)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / reductions "
+                    "(nccl = RCCL; gloo only for rehearsing the N>1 path on a one-GPU box)")
     ap.add_argument("--no-variants", dest="variants", action="store_false",
                     help="skip the extra (distribution, data_type) rows")
     args = ap.parse_args()
@@ -211,12 +215,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    local = local % max(torch.cuda.device_count(), 1)  # (rehearsal: several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist_on = world > 1
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     hc = importlib.import_module("hipcomp-core_amd")
     lib = hc.default_library()

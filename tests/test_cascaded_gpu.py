@@ -122,3 +122,26 @@ def test_host_side_errors(hc, cuda):
     assert toomany.compress_async(src, 400, None, dst) == hc.hipcompStatus.ErrorInvalidValue
     lib = hc.default_library()
     assert lib.hipcompBatchedCascadedDecompressAsync(None, None, None, None, 1, None, 0, None, None, None) == 10
+
+
+def test_large_partitions(hc, oracle, reflib, cuda):
+    """Partitions of many 4096-byte sub-chunks, incl. a ragged last one."""
+    import torch
+    chunks = [_sorted_column(3, 262144).tobytes(), _sorted_column(4, 100003).astype(np.uint16).tobytes() + b"\x07",
+              np.repeat(np.arange(5000, dtype=np.int64), 37).tobytes()]
+    for t, c in zip((5, 3, 6), chunks):
+        src = hc.batch.from_host_chunks([c], "cuda:0")
+        copts = hc.CascadedOpts(4096, t, 2, 1, 1)
+        codec = hc.batch.Codec("Cascaded", copts)
+        mine = codec.compress(src)
+        torch.cuda.synchronize()
+        want, mask = oracle.cascaded_compress(c, t, 2, 1, 1)
+        assert mine.to_host_chunks()[0] == want
+        if reflib is not None:
+            r = hc.batch.Codec("Cascaded", copts, lib=reflib).compress(src)
+            torch.cuda.synchronize()
+            assert oracle.masked_equal(r.to_host_chunks()[0], want, mask)
+        s = oracle.CASCADED_TYPE_SIZE[t]
+        dec, actual, statuses = codec.decompress(mine, len(c) + 16)
+        assert statuses.cpu().tolist() == [0]
+        assert dec.to_host_chunks()[0] == c[: len(c) // s * s]

@@ -181,3 +181,22 @@ def test_host_side_errors(hc, cuda):
     out = ctypes.c_size_t(0)
     assert lib.hipcompBatchedLZ4CompressGetTempSize(1, (1 << 24) + 1, hc.LZ4Opts(0), ctypes.byref(out)) == 10
     assert lib.hipcompBatchedLZ4CompressGetMaxOutputChunkSize((1 << 24) + 1, hc.LZ4Opts(0), ctypes.byref(out)) == 10
+
+
+def test_maximum_chunk_size_16MiB(hc, oracle, cuda):
+    """The API's largest chunk (16 MiB): sizes, round trip, oracle equality on
+    a compressible input (the oracle walks 16 Mi positions: keep it to one)."""
+    import torch
+    n = 1 << 24
+    rng = np.random.default_rng(2)
+    base = datagen.text_like(9, 1 << 16)
+    data = (base * (n // len(base) + 1))[:n]
+    src = hc.batch.from_host_chunks([data], "cuda:0")
+    codec = hc.batch.Codec("LZ4")
+    mine = codec.compress(src, n)
+    torch.cuda.synchronize()
+    got = mine.to_host_chunks()[0]
+    assert got == oracle.lz4_compress(data, 1, n)
+    dec, actual, statuses = codec.decompress(mine, n)
+    assert statuses.cpu().tolist() == [0] and actual.cpu().tolist() == [n]
+    assert dec.to_host_chunks()[0] == data

@@ -117,3 +117,26 @@ def test_decoder_error_paths_match_oracle(hc, oracle, cuda):
                 assert dec.chunk_bytes(i, ac[i]) == obytes
     sizes = hc.batch.Codec("Snappy").get_decompress_size(hc.batch.from_host_chunks(streams, "cuda:0")).cpu().tolist()
     assert sizes == [oracle.snappy_uncompressed_size(s) for s in streams]
+
+
+def test_large_chunks(hc, oracle, reflib, cuda):
+    """Chunks far beyond 64 KiB: the 16-bit hash-map positions wrap and copy
+    distances stay <= 32768."""
+    import torch
+    rng = np.random.default_rng(8)
+    chunks = [datagen.tpch_lineitem_text(5, 300000), datagen.text_like(6, 1 << 20),
+              bytes(rng.integers(0, 4, 200001, dtype=np.uint8)), bytes(rng.integers(0, 256, 150000, dtype=np.uint8))]
+    src = hc.batch.from_host_chunks(chunks, "cuda:0")
+    codec = hc.batch.Codec("Snappy")
+    mine = codec.compress(src)
+    torch.cuda.synchronize()
+    got = mine.to_host_chunks()
+    for i, c in enumerate(chunks):
+        assert got[i] == oracle.snappy_compress(c), i
+    if reflib is not None:
+        r = hc.batch.Codec("Snappy", lib=reflib).compress(src)
+        torch.cuda.synchronize()
+        assert r.to_host_chunks() == got
+    dec, actual, statuses = codec.decompress(mine, 1 << 20)
+    assert statuses.cpu().tolist() == [0] * len(chunks)
+    assert dec.to_host_chunks() == chunks

@@ -8,7 +8,8 @@
 //     LZ4Batch.cpp:76,160,177 call CHECK_NOT_NULL outside the try block);
 //   * batch_size == 0 is a successful no-op (the reference launches a
 //     zero-sized grid and reports the resulting HIP error);
-//   * the hash table lives in LDS, so device_temp_ptr is never dereferenced.
+//   * the hash tables live in LDS; of device_temp_ptr only the first 4 bytes
+//     are used (the chunk ticket counter of the persistent compress kernel).
 //     temp_bytes is still checked against the contract size so that callers
 //     sized for the reference keep working and callers that under-allocate
 //     keep failing the same way.
@@ -87,7 +88,7 @@ hipcompStatus_t hipcompBatchedLZ4CompressAsync(
     const void* const* device_uncompressed_ptrs,
     const size_t* device_uncompressed_bytes,
     size_t max_uncompressed_chunk_bytes, size_t batch_size,
-    void* /*device_temp_ptr*/, size_t temp_bytes,
+    void* device_temp_ptr, size_t temp_bytes,
     void* const* device_compressed_ptrs, size_t* device_compressed_bytes,
     hipcompBatchedLZ4Opts_t format_opts, hipStream_t stream)
 {
@@ -107,12 +108,18 @@ hipcompStatus_t hipcompBatchedLZ4CompressAsync(
     return fail(fn, "Unsupported input data type");
   if (batch_size == 0)
     return hipcompSuccess;
+  if (batch_size > 0xFFFFFFFFull)
+    return fail(fn, "batch_size must be below 2^32");
+  HCAMD_DEVICE_POINTER(fn, device_temp_ptr);
 
-  lz4_launch_compress(
+  const hipError_t e = lz4_launch_compress(
       reinterpret_cast<const uint8_t* const*>(device_uncompressed_ptrs),
       device_uncompressed_bytes,
       reinterpret_cast<uint8_t* const*>(device_compressed_ptrs),
-      device_compressed_bytes, (uint32_t)ht, batch_size, s, stream);
+      device_compressed_bytes, (uint32_t)ht, batch_size, s,
+      static_cast<uint32_t*>(device_temp_ptr), stream);
+  if (e != hipSuccess)
+    return fail(fn, std::string("lz4 compress launch: ") + hipGetErrorString(e));
   std::string why;
   if (!launch_ok("lz4 compress kernel", why))
     return fail(fn, why);

@@ -197,39 +197,57 @@ __device__ __forceinline__ uint32_t match_length(
   return limit;
 }
 
+// Workgroup shape: the hash table (ht_size x u16, 32 KiB for 64 KiB chunks)
+// is the only LDS user and LDS is what limits residency.  The CU allocates
+// LDS in 1280-byte granules, so five separate 32 KiB workgroups do not fit
+// into its 160 KiB (5 x 26 granules) but ONE workgroup of five waves with
+// 5 x 32 KiB does.  Each wave of the workgroup owns one table and takes
+// chunks from a global ticket counter until the batch is exhausted; the waves
+// never synchronise with each other.
 template <int S>
-__global__ __launch_bounds__(kWave) void lz4_compress_kernel(
+__global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_kernel(
     const uint8_t* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     uint8_t* const* __restrict__ out_ptrs,
     size_t* __restrict__ out_bytes,
-    const uint32_t ht_size)
+    const uint32_t ht_size,
+    const uint32_t table_stride,
+    const uint32_t batch,
+    uint32_t* __restrict__ ticket)
 {
-  // LDS holds the hash table and nothing else: 16384 x u16 = 32 KiB per
-  // chunk, so five chunks are resident per CU (5 x 32 KiB = the CU's 160 KiB).
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint16_t* table = reinterpret_cast<uint16_t*>(smem);
 
   constexpr uint32_t LVM = (12 + S - 1) / S; // last valid match, elements
   constexpr uint32_t MEL = (5 + S - 1) / S;  // min ending literals, elements
   constexpr int INV = 3 / S;                 // lanes without a full 4-byte word
   constexpr int NVMAX = kWave - INV;
 
-  const int lane = (int)threadIdx.x;
-  const size_t chunk = blockIdx.x;
-  cgptr __restrict__ in = to_global(in_ptrs[chunk]);
-  const uint32_t len = (uint32_t)in_bytes[chunk];
-  gptr __restrict__ out = to_global(out_ptrs[chunk]);
-  const uint32_t L = (len + S - 1) / S;
+  const int lane = lane_id();
+  const uint32_t wave = uniform((uint32_t)(threadIdx.x >> 6));
+  uint8_t* const my_smem = smem + wave * table_stride;
+  uint16_t* const table = reinterpret_cast<uint16_t*>(my_smem);
   const uint32_t hmask = ht_size - 1;
   const InsertPerm perm = make_insert_perm(lane);
   const uint32_t rev_lane = 63u - (uint32_t)lane;
   const int rev_addr4 = (int)(rev_lane * 4u);
 
+ for (;;) {
+  // Every lane takes part in the atomic (lane 0 adds 1, the others 0): a
+  // `if (lane == 0)` here sits back to back with the `if (lane == 0)` store
+  // that ends the previous chunk, the compiler threads the two together and
+  // the readfirstlane below then runs with lane 0 split off (seen as a hang).
+  const uint32_t chunk = uniform(atomicAdd(ticket, lane == 0 ? 1u : 0u));
+  if (chunk >= batch)
+    break;
+  cgptr __restrict__ in = to_global(in_ptrs[chunk]);
+  const uint32_t len = (uint32_t)in_bytes[chunk];
+  gptr __restrict__ out = to_global(out_ptrs[chunk]);
+  const uint32_t L = (len + S - 1) / S;
+
   // ---- LDS init (reference :815-818 fills the table with NULL_OFFSET)
   {
     u32x4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    u32x4* p = reinterpret_cast<u32x4*>(smem);
+    u32x4* p = reinterpret_cast<u32x4*>(my_smem);
     const uint32_t nvec = ((ht_size * 2 + 15) & ~15u) >> 4;
     for (uint32_t i = (uint32_t)lane; i < nvec; i += kWave)
       p[i] = ones;
@@ -401,6 +419,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_kernel(
   }
   if (lane == 0)
     out_bytes[chunk] = c;
+ } // next ticket
 }
 
 // --------------------------------------------------------------------------
@@ -534,27 +553,73 @@ size_t lz4_compress_lds_bytes(uint32_t ht_size)
   return (ht_size * 2 + 15) & ~15u;
 }
 
-void lz4_launch_compress(
+Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch)
+{
+  static const int num_cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess
+        || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  constexpr uint32_t kLdsPerCu = 160u * 1024u;
+  Lz4CompressShape sh;
+  sh.table_stride = (uint32_t)lz4_compress_lds_bytes(ht_size);
+  uint32_t w = kLdsPerCu / sh.table_stride;
+  if (w > (uint32_t)kLz4MaxWavesPerGroup)
+    w = kLz4MaxWavesPerGroup;
+  if ((size_t)w > batch)
+    w = (uint32_t)batch;
+  sh.waves = w;
+  sh.lds_bytes = w * sh.table_stride;
+  // enough workgroups to occupy every CU; late ones find the ticket counter
+  // exhausted and leave at once
+  const size_t per_cu = kLdsPerCu / sh.lds_bytes;
+  const size_t want = (batch + w - 1) / w;
+  const size_t cap = (size_t)num_cus * (per_cu > 4 ? 4 : per_cu);
+  sh.groups = (uint32_t)(want < cap ? want : cap);
+  return sh;
+}
+
+hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, hipStream_t stream)
+    size_t batch, int elem_size, uint32_t* ticket, hipStream_t stream)
 {
-  const dim3 grid((unsigned)batch), block(kWave);
-  const size_t lds = lz4_compress_lds_bytes(ht_size);
+  const Lz4CompressShape sh = lz4_compress_shape(ht_size, batch);
+  const dim3 grid(sh.groups), block(sh.waves * kWave);
+  hipError_t e = hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess)
+    return e;
+  // more than 64 KiB of dynamic LDS has to be asked for, once per kernel
+  static const hipError_t raised = [] {
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (r == hipSuccess)
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (r == hipSuccess)
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return r;
+  }();
+  if (raised != hipSuccess)
+    return raised;
   switch (elem_size) {
   case 1:
-    lz4_compress_kernel<1><<<grid, block, lds, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size);
+    lz4_compress_kernel<1><<<grid, block, sh.lds_bytes, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket);
     break;
   case 2:
-    lz4_compress_kernel<2><<<grid, block, lds, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size);
+    lz4_compress_kernel<2><<<grid, block, sh.lds_bytes, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket);
     break;
   default:
-    lz4_compress_kernel<4><<<grid, block, lds, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size);
+    lz4_compress_kernel<4><<<grid, block, sh.lds_bytes, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket);
     break;
   }
+  return hipSuccess;
 }
 
 void lz4_launch_decompress(

@@ -9,13 +9,30 @@
 
 namespace hcamd {
 
-// Dynamic LDS one compression workgroup (= one chunk) needs.
+// LDS bytes of one chunk's hash table.
 size_t lz4_compress_lds_bytes(uint32_t ht_size);
 
-void lz4_launch_compress(
+// Most waves (= chunks in flight) one compression workgroup holds.
+constexpr int kLz4MaxWavesPerGroup = 16;
+
+// Launch shape of the compression kernel: `waves` chunks in flight per
+// workgroup, each with its own `table_stride` bytes of LDS.
+struct Lz4CompressShape
+{
+  uint32_t waves;
+  uint32_t table_stride;
+  uint32_t lds_bytes;
+  uint32_t groups;
+};
+Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch);
+
+// `ticket` is one zero-initialised-by-the-launcher uint32 in device memory
+// (the start of the caller's temp buffer) from which waves draw chunk
+// numbers.  batch must be > 0 and < 2^32.
+hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, hipStream_t stream);
+    size_t batch, int elem_size, uint32_t* ticket, hipStream_t stream);
 
 // write_out == false: parse-only pass that reports sizes.
 void lz4_launch_decompress(

@@ -1,0 +1,21 @@
+"""Diagnostic: per-segment cycle shares of the LZ4 compress window loop (HC_STAMPS build)."""
+import ctypes, importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, bench
+hc = importlib.import_module("hipcomp-core_amd")
+lib = hc.HipcompLibrary(os.path.join(ROOT, "hipcomp-core_amd/lib/libhipcomp_stamps.so"), codecs=("LZ4",))
+dist, dtype = sys.argv[1], sys.argv[2]
+data = bench.gen_data(dist, 5000, torch.device("cuda:0"), 0x5EED0002)
+job = bench.Lz4Job(hc, lib, data, hc.hipcompType.CHAR if dtype == "char" else hc.hipcompType.INT)
+job.compress(); torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 16)()
+f = lib._dll.hipcompBatchedLZ4DebugStamps
+f.argtypes = [ctypes.c_void_p]
+assert f(out) == 0
+v = list(out)[:8]; tot = sum(v)
+names = ["0 window wait+hash", "1 table read + mirror bperm", "2 issue loads, marker, readback", "3 word bperm, ballots, dup decision",
+         "4 verify wait + table decision", "5 insert", "6 rest (final literals / match path)", "7"]
+print(dist, dtype, "total Gcycles", tot / 1e9)
+for n, x in zip(names, v):
+    print(f"  {n:40s} {100 * x / tot:5.1f} %")

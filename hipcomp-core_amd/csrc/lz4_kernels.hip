@@ -15,8 +15,8 @@
 //                                           fallback only for colliding lanes
 //   second warpMatchAny for the insert      insert rule (incl. the wave64
 //   (:722-741) + hardware arbitration of    `int` truncation)
-//   same-address global_store_short         expressed as two ordered masked
-//                                           LDS stores (see insert_window)
+//   same-address global_store_short         expressed as ONE lane-permuted masked
+//                                           LDS store (see insert_image)
 //   shuffleLiterals (:754-791)              one unaligned dword load per lane
 //   1 byte/lane literal + match compare     16-byte/lane copies, 4-byte/lane
 //                                           match-length compare
@@ -110,52 +110,77 @@ __device__ __forceinline__ uint32_t write_sequence(
 //              for q in 0..3: lane 16g+4q+p,  last write survives.
 //
 // Mechanism here: ds_write_b16 keeps the HIGHEST lane among lanes that hit
-// one address (measured, same test), so
-//   store 1: lanes >= 32, with the lanes permuted (ds_bpermute) so that lane
-//            order equals the hardware's write order above;
-//   store 2: lanes 0..30 (not in lane 31's slot), natural order -- it
-//            overrides store 1 wherever a slot has a lane below 32.
+// one address (measured, same test), so the whole rule is ONE store whose
+// lanes are permuted (ds_bpermute) into priority order:
+//   physical lanes  0..31: window lanes >= 32 in the hardware's write order
+//                          above (the reference's global_store_short);
+//   physical lanes 32..63: window lanes 0..31 in natural order -- they
+//                          override the first half wherever a slot also has
+//                          a window lane below 32.
+// What travels through the permute is the "insert image" of a window lane:
+// bits 0..13 slot, bit 14 "this lane stores", bits 16..31 the value.
 // ---------------------------------------------------------------------------
-struct InsertPerm
-{
-  uint32_t src_lane;  // lane whose (slot,position) this lane stores in store 1
-  uint32_t src_addr4; // 4 * src_lane (ds_bpermute byte address)
-};
+constexpr uint32_t kImageStore = 1u << 14;
 
-__device__ __forceinline__ InsertPerm make_insert_perm(int lane)
+__device__ __forceinline__ int make_insert_perm_addr4(int lane)
 {
-  InsertPerm p;
+  uint32_t src;
   if (lane < 32) {
-    p.src_lane = (uint32_t)lane;
+    const uint32_t r = (uint32_t)lane;
+    src = 32u + (r & 16u) + 4u * (r & 3u) + (3u - ((r >> 2) & 3u));
   } else {
-    const uint32_t r = (uint32_t)lane - 32u;
-    p.src_lane = 32u + (r & 16u) + 4u * (r & 3u) + (3u - ((r >> 2) & 3u));
+    src = (uint32_t)lane - 32u;
   }
-  p.src_addr4 = p.src_lane * 4u;
-  return p;
+  return (int)(src * 4u);
 }
 
-__device__ __forceinline__ void insert_window(
-    uint16_t* table, uint32_t hpos, uint32_t d, int n, int lane,
-    const InsertPerm& perm)
+// Insert image of this window lane for an insert of the first n >= 32 window
+// lanes.  restore31: lane 31's slot keeps its old content under the rule, so
+// lane 31 can carry that old content (slot_old) instead -- used to undo the
+// duplicate-search marker of that slot in the same store.
+template <int NVMAX>
+__device__ __forceinline__ uint32_t insert_image(
+    uint32_t hpos, uint32_t pos, uint32_t slot_old, int n, int lane, bool restore31)
 {
-  if (n <= 31) {
-    if (lane < n)
-      table[hpos] = (uint16_t)((d + (uint32_t)lane) & 0xFFFFu);
-    return;
-  }
   const uint32_t h31 = read_lane(hpos, 31);
-  const bool in31 = (hpos == h31);
-  const bool hi = lane >= 32 && lane < n && (!in31 || lane == 63);
-  // store 1 (permuted): bit 31 carries the "this lane stores" flag
-  const uint32_t packed = hpos | (hi ? 0x80000000u : 0u);
-  const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(
-      (int)perm.src_addr4, (int)packed);
-  if (lane >= 32 && (got & 0x80000000u))
-    table[got & 0x7FFFFFFFu] = (uint16_t)((d + perm.src_lane) & 0xFFFFu);
-  // store 2
-  if (lane < 31 && !in31)
-    table[hpos] = (uint16_t)((d + (uint32_t)lane) & 0xFFFFu);
+  const bool in31 = hpos == h31;
+  // lane 63 takes part only in a full 64-lane window
+  const bool l63_in31 = NVMAX == 64 && n == 64 && read_lane(hpos, 63) == h31;
+  bool store;
+  if (lane < 31)
+    store = !in31;
+  else if (lane == 31)
+    store = restore31 && !l63_in31;
+  else
+    store = lane < n && (!in31 || lane == 63);
+  const uint32_t value = lane == 31 ? slot_old : pos;
+  return hpos | (store ? kImageStore : 0u) | (value << 16);
+}
+
+__device__ __forceinline__ void store_insert_image(uint16_t* table, uint32_t image)
+{
+  if (image & kImageStore)
+    table[image & (kImageStore - 1u)] = (uint16_t)(image >> 16);
+}
+
+// n <= 31: plain store of the first n lanes.
+__device__ __forceinline__ void insert_short_window(
+    uint16_t* table, uint32_t hpos, uint32_t pos, int n, int lane)
+{
+  if (lane < n)
+    table[hpos] = (uint16_t)pos;
+}
+
+// table[slot] and ds_bpermute issued back to back, ONE wait for both (left to
+// itself the compiler waits for the read, then issues the permute).
+__device__ __forceinline__ void lds_read_u16_with_bpermute(
+    const uint16_t* slot, int bp_addr4, uint32_t bp_data, uint32_t& slot_value, uint32_t& bp_value)
+{
+  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t*)slot;
+  asm volatile("ds_read_u16 %0, %2\n\tds_bpermute_b32 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(slot_value), "=&v"(bp_value)
+               : "v"(a), "v"(bp_addr4), "v"(bp_data)
+               : "memory");
 }
 
 // First mismatching element between the strings at elements `prev` and `pos`
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   uint8_t* const my_smem = smem + wave * table_stride;
   uint16_t* const table = reinterpret_cast<uint16_t*>(my_smem);
   const uint32_t hmask = ht_size - 1;
-  const InsertPerm perm = make_insert_perm(lane);
+  const int perm_addr4 = make_insert_perm_addr4(lane);
   const uint32_t rev_lane = 63u - (uint32_t)lane;
   const int rev_addr4 = (int)(rev_lane * 4u);
 
@@ -254,13 +279,17 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   }
 
   uint32_t d = 0, c = 0;
-  // `next` of the window at d when have_next (prefetched by the previous,
-  // match-less iteration)
-  uint32_t next = 0;
-  bool have_next = false;
   // highest element with 4 readable bytes; windows exist only while
   // d + LVM < L, so the clamp below is only ever used with L > LVM
   const uint32_t last_word = L > LVM ? L - LVM - 1 : 0;
+  // window word of lane t = the 4 bytes at element d+t (reference :848-854;
+  // for every lane < nv none of them is masked).  It is always loaded one
+  // window ahead, unconditionally and with a clamped, always readable index,
+  // so that the compiler can count the loads: a load under a branch would
+  // force s_waitcnt vmcnt(0) at the first use of ANY older load.
+  uint32_t next = 0;
+  if (L > LVM)
+    next = load_u32_any(in + (size_t)min((uint32_t)lane, last_word) * S);
 
   while (d < L) {
     const uint32_t token_start = d;
@@ -276,24 +305,17 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
       const uint64_t vmask = lanes_below<NVMAX>(nv);
       const bool valid = lane < nv;
       const uint32_t pos = d + (uint32_t)lane;
-
-      // window word of lane t = the 4 bytes at element d+t (reference
-      // :848-854; for every lane < nv none of them is masked).  Loads are
-      // unconditional with a clamped, always readable index so that the
-      // compiler can count them: a load under a branch would force
-      // s_waitcnt vmcnt(0) at the first use of ANY older load.
-      if (!have_next)
-        next = load_u32_any(in + (size_t)min(pos, last_word) * S);
       const uint32_t hpos = hash_sum(next) & hmask;
 
+      // LDS round trip 1 of 3.
       // (B) candidate from earlier windows (reference isValidHash :634-663,
       // convertIdx :619-632).  The table read needs no mask: hpos is always
       // inside the table.
-      const uint32_t h_old = table[hpos];
       // (A) in-window duplicates, step 1: my slot and "I am a valid lane" go
-      // to the mirrored lane (see below); issued together with the table read
-      const uint32_t pr = (uint32_t)__builtin_amdgcn_ds_bpermute(
-          rev_addr4, (int)(hpos | (valid ? 0x80000000u : 0u)));
+      // to the mirrored lane (see below).
+      uint32_t h_old, pr;
+      lds_read_u16_with_bpermute(
+          table + hpos, rev_addr4, hpos | (valid ? 0x80000000u : 0u), h_old, pr);
 
       uint32_t cand = (pos & ~0xFFFFu) + h_old;
       if (cand >= pos)
@@ -318,6 +340,14 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
       const uint32_t next_pf = load_u32_any(
           in + (size_t)min(pos + (uint32_t)nv, last_word) * S);
 
+      // What the table insert of a window WITHOUT a match stores (all nv
+      // lanes, reference :958-962), prepared before the match decision so
+      // that its lane permute rides along with round trip 2.  It also puts
+      // back the one marker (below) that this insert does not overwrite.
+      const bool full_insert = nv >= 32; // uniform
+      const uint32_t image
+          = insert_image<NVMAX>(hpos, pos & 0xFFFFu, h_old, nv, lane, true);
+
       // (A) in-window duplicates: lowest lane holding my word, found through
       // the hash table itself (no scratch LDS).  Every valid lane posts its
       // lane id into its own table slot with the lanes in REVERSED order, so
@@ -327,16 +357,18 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
       // different words share the slot and the lane is settled by the exact
       // fallback below.  The slots are then put back (h_old) before the real
       // insert.
+      // LDS round trip 2: markers out, winner of my slot and the permuted
+      // insert image back.
       lds_lane_exchange_fence();
       if (pr & 0x80000000u)
         table[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
       lds_lane_exchange_fence();
       const uint32_t w_raw = table[hpos];
-      lds_lane_exchange_fence();
-      if (valid)
-        table[hpos] = (uint16_t)h_old;
+      const uint32_t permuted_image
+          = (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)image);
       lds_lane_exchange_fence();
       const uint32_t w = valid ? w_raw : (uint32_t)lane;
+      // LDS round trip 3: the word of that winner
       const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)next);
       // masks are combined as scalars: each ballot is one v_cmp.  (An
       // invalid lane has w == lane, so it can be neither dup nor unresolved.)
@@ -374,7 +406,16 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
       if (tmask != 0 || in_window) {
         // reference :925-956
         const uint32_t match_location = tmask ? tcand : d + mlane;
-        insert_window(table, hpos, d, f, lane, perm);
+        // markers off, then the first f lanes go into the table
+        if (valid)
+          table[hpos] = (uint16_t)h_old;
+        lds_lane_exchange_fence();
+        if (f >= 32) {
+          const uint32_t im = insert_image<NVMAX>(hpos, pos & 0xFFFFu, 0, f, lane, false);
+          store_insert_image(table, (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)im));
+        } else {
+          insert_short_window(table, hpos, pos & 0xFFFFu, f, lane);
+        }
         const uint32_t mpos = d + (uint32_t)f;
         const uint32_t off_elems = (mpos - match_location) & 0xFFFFu;
         const uint32_t lit = mpos - token_start;
@@ -407,14 +448,20 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
                              match_bytes, offset_bytes, lane);
         }
         d = token_start + lit + ml;
-        have_next = false;
+        next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
         break;
       }
       // no match in this window (reference :958-962)
-      insert_window(table, hpos, d, nv, lane, perm);
+      if (full_insert) {
+        store_insert_image(table, permuted_image);
+      } else {
+        if (valid)
+          table[hpos] = (uint16_t)h_old;
+        lds_lane_exchange_fence();
+        insert_short_window(table, hpos, pos & 0xFFFFu, nv, lane);
+      }
       d += (uint32_t)nv;
       next = next_pf;
-      have_next = true;
     }
   }
   if (lane == 0)

@@ -183,6 +183,191 @@ __device__ __forceinline__ void lds_read_u16_with_bpermute(
                : "memory");
 }
 
+// Same with a second ds_bpermute in the group (the pipelined walk: the word of
+// the previous window's slot winners travels with the new window's lookup).
+__device__ __forceinline__ void lds_read_u16_with_2bpermutes(
+    const uint16_t* slot, int bp1_addr4, uint32_t bp1_data, int bp2_addr4, uint32_t bp2_data,
+    uint32_t& slot_value, uint32_t& bp1_value, uint32_t& bp2_value)
+{
+  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t*)slot;
+  asm volatile("ds_read_u16 %0, %3\n\tds_bpermute_b32 %1, %4, %5\n\tds_bpermute_b32 %2, %6, %7\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(slot_value), "=&v"(bp1_value), "=&v"(bp2_value)
+               : "v"(a), "v"(bp1_addr4), "v"(bp1_data), "v"(bp2_addr4), "v"(bp2_data)
+               : "memory");
+}
+
+// ---------------------------------------------------------------------------
+// One window of the match search = 64 consecutive element positions, one per
+// lane (reference :847-962).  Its work comes in two halves:
+//   table half    hash, table lookup, candidate verification load, search
+//                 markers, table insert;
+//   decision half first lane with a match (in-window duplicate or verified
+//                 table candidate).
+// ---------------------------------------------------------------------------
+struct Window
+{
+  uint32_t d;         // first element (wave-uniform)
+  int nv;             // lanes holding a position that may start a match (uniform)
+  bool valid;         // lane < nv
+  uint32_t word;      // the 4 bytes at element d + lane
+  uint32_t hpos;      // my table slot
+  uint32_t h_old;     // what the slot held before this window
+  uint32_t cand;      // element the slot points to
+  bool probe;         // the candidate is usable: verify its word
+  uint32_t cand_word; // 4 bytes at cand (in flight until first use)
+  uint32_t next_word; // 4 bytes at element d + nv + lane (in flight)
+  uint32_t w_raw;     // marker read back from my slot: lowest lane in it
+  uint32_t pimage;    // lane-permuted insert image of the whole window
+};
+
+struct Decision
+{
+  bool match;
+  int f;                   // first lane with a match
+  uint32_t match_location; // element it matches
+};
+
+template <int S, int NVMAX>
+__device__ __forceinline__ void window_begin(
+    Window& W, uint32_t d, uint32_t word, uint32_t L, uint32_t hmask, int lane)
+{
+  constexpr uint32_t LVM = (12 + S - 1) / S;
+  W.d = d;
+  W.nv = min(NVMAX, (int)(L - d - LVM)); // >= 1
+  W.valid = lane < W.nv;
+  W.word = word;
+  W.hpos = hash_sum(word) & hmask;
+}
+
+// (B) candidate from earlier windows (reference isValidHash :634-663,
+// convertIdx :619-632), its 4-byte verify load, then the load of the next
+// window's words: the latter is issued AFTER the verify so that waiting for the
+// verify (in-order vmcnt) does not wait for it.  Both loads are unconditional
+// with a clamped, always readable index so that the compiler can count them.
+template <int S>
+__device__ __forceinline__ void window_candidate(
+    Window& W, cgptr in, uint32_t last_word, int lane, bool load_next = true)
+{
+  const uint32_t pos = W.d + (uint32_t)lane;
+  uint32_t cand = (pos & ~0xFFFFu) + W.h_old;
+  if (cand >= pos)
+    cand -= 65536u;
+  // The reference accepts any candidate within 65535 ELEMENTS and then
+  // truncates the byte offset to 16 bits (:651, :954), which corrupts
+  // typed-mode (S > 1) streams of chunks larger than 64 KiB.  Candidates
+  // whose byte distance does not fit are rejected here; for chunks
+  // <= 64 KiB this never triggers, so those stay bit-identical
+  // (DESIGN.md "deliberate deviations").
+#ifdef HC_ABL_NO_VERIFY
+  W.probe = false;
+#else
+  W.probe = W.valid && W.h_old != kNullOffset && (pos - cand) * S <= 65535u;
+#endif
+  W.cand = cand;
+  W.cand_word = load_u32_any(in + (size_t)(W.probe ? cand : min(pos, last_word)) * S);
+  // (not after a window with a match: this one most likely has one too, the
+  // words would be dropped, and a load in flight into a register the match
+  // path wants to reuse makes that path wait for it)
+  if (load_next)
+    W.next_word = load_u32_any(in + (size_t)min(pos + (uint32_t)W.nv, last_word) * S);
+}
+
+// (A) in-window duplicates: lowest lane holding my word, found through the
+// hash table itself (no scratch LDS).  Every valid lane posts its lane id into
+// its own table slot with the lanes in REVERSED order (`pr` = slot and valid
+// flag of the mirrored lane), so that ds_write_b16's "highest lane wins"
+// leaves the LOWEST window lane of each slot; reading the slot back names that
+// lane.  If it holds my word it is exactly min{u : word_u == word_t};
+// otherwise two different words share the slot and the lane is settled by the
+// exact fallback in window_decide.
+// The same LDS round trip carries the lane permute of the insert image of a
+// window WITHOUT a match (all nv lanes, reference :958-962); storing that image
+// overwrites every marker but the one of lane 31's slot, whose old content the
+// image carries (insert_image).  Nothing is waited for here.
+template <int NVMAX>
+__device__ __forceinline__ void window_markers(
+    Window& W, uint16_t* table, uint32_t pr, uint32_t rev_lane, int perm_addr4, int lane)
+{
+  const uint32_t image = insert_image<NVMAX>(
+      W.hpos, (W.d + (uint32_t)lane) & 0xFFFFu, W.h_old, W.nv, lane, true);
+  lds_lane_exchange_fence();
+  if (pr & 0x80000000u)
+    table[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
+  lds_lane_exchange_fence();
+  W.w_raw = table[W.hpos];
+  W.pimage = (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)image);
+  lds_lane_exchange_fence();
+}
+
+__device__ __forceinline__ uint32_t window_winner(const Window& W, int lane)
+{
+  // an invalid lane names itself, so it is neither duplicate nor unresolved
+  return W.valid ? W.w_raw : (uint32_t)lane;
+}
+
+// nw = word of window_winner's lane (one ds_bpermute, issued by the caller).
+template <int NVMAX>
+__device__ __forceinline__ Decision window_decide(const Window& W, uint32_t nw, int lane)
+{
+  const uint64_t vmask = lanes_below<NVMAX>(W.nv);
+  const uint32_t w = window_winner(W, lane);
+  // masks are combined as scalars: each ballot is one v_cmp
+  const uint64_t eqmask = wave_ballot(nw == W.word);
+  const uint64_t dupmask = eqmask & wave_ballot(w != (uint32_t)lane);
+  const uint64_t unres = vmask & ~eqmask;
+
+  // first lane with an equal lower lane (nv if none) and that lower lane
+  int f = dupmask ? __builtin_ctzll(dupmask) : W.nv;
+  uint32_t mlane = read_lane(w, f & 63);
+  uint64_t U = unres & lanes_below<NVMAX>(f);
+  if (__builtin_expect(U != 0, 0)) {
+    do {
+      const int u = __builtin_ctzll(U);
+      U &= U - 1;
+      const uint32_t v = read_lane(W.word, u);
+      const uint64_t m = wave_ballot(W.word == v) & vmask;
+      const int lo = __builtin_ctzll(m);
+      if (lo != u) {
+        f = u;
+        mlane = (uint32_t)lo;
+        break;
+      }
+    } while (U);
+  }
+  // earliest lane (< f) with a verified table candidate wins
+  // (reference :896-923)
+  const uint64_t tmask
+      = wave_ballot(W.cand_word == W.word) & wave_ballot(W.probe) & lanes_below<NVMAX>(f);
+  const bool in_window = f < W.nv;
+  if (tmask)
+    f = __builtin_ctzll(tmask);
+  const uint32_t tcand = read_lane(W.cand, f & 63);
+  Decision D;
+  D.match = tmask != 0 || in_window;
+  D.f = f;
+  D.match_location = tmask ? tcand : W.d + mlane; // reference :925-956
+  return D;
+}
+
+// Table state "only the first f lanes of W were inserted", from any state in
+// which W's slots hold markers or W's full insert.
+template <int NVMAX>
+__device__ __forceinline__ void window_insert_first(
+    const Window& W, uint16_t* table, int f, int perm_addr4, int lane)
+{
+  const uint32_t pos16 = (W.d + (uint32_t)lane) & 0xFFFFu;
+  if (W.valid)
+    table[W.hpos] = (uint16_t)W.h_old;
+  lds_lane_exchange_fence();
+  if (f >= 32) {
+    const uint32_t im = insert_image<NVMAX>(W.hpos, pos16, 0, f, lane, false);
+    store_insert_image(table, (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)im));
+  } else {
+    insert_short_window(table, W.hpos, pos16, f, lane);
+  }
+}
+
 // First mismatching element between the strings at elements `prev` and `pos`
 // (reference lengthOfMatch :592-617), compared 4 bytes per lane per step.
 template <int S>
@@ -222,6 +407,48 @@ __device__ __forceinline__ uint32_t match_length(
   return limit;
 }
 
+// The sequence that ends with the match D found in the window at element wd
+// (words `word`): literals from token_start, match, offset (reference
+// writeSequenceData :665-715).  Returns the new output cursor in c and the
+// element after the match in d_after.
+template <int S>
+__device__ __forceinline__ void emit_match(
+    gptr out, uint32_t& c, cgptr in, uint32_t token_start, uint32_t wd, uint32_t word,
+    const Decision& D, uint32_t L, int lane, uint32_t& d_after)
+{
+  constexpr uint32_t MEL = (5 + S - 1) / S; // min ending literals, elements
+  const uint32_t mpos = wd + (uint32_t)D.f;
+  const uint32_t off_elems = (mpos - D.match_location) & 0xFFFFu;
+  const uint32_t lit = mpos - token_start;
+  const uint32_t ml = match_length<S>(in, D.match_location, mpos, L - mpos - MEL, lane);
+  const uint32_t lit_bytes = lit * S, match_bytes = ml * S;
+  const uint32_t offset_bytes = (off_elems * S) & 0xFFFFu;
+  if (token_start == wd && lit_bytes < 15 && match_bytes < 19) {
+    // Fast path: the whole sequence started in this window and is short, so
+    // its literal bytes are the low bytes of the lanes' window words: token,
+    // literals and offset leave as byte stores straight from registers.
+    // Byte i of the sequence: 0 = token, 1..lit_bytes = literals, then
+    // offset lo, hi.
+    const uint32_t i = (uint32_t)lane;
+    const uint32_t li = i - 1; // literal byte index
+    const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((li / S) * 4u), (int)word);
+    uint32_t bt = (src >> (8u * (li % S))) & 0xFFu;
+    if (i == 0)
+      bt = (lit_bytes << 4) | ((match_bytes - 4u) & 0x0Fu);
+    else if (i == lit_bytes + 1)
+      bt = offset_bytes & 0xFFu;
+    else if (i == lit_bytes + 2)
+      bt = offset_bytes >> 8;
+    if (i < lit_bytes + 3)
+      out[c + i] = (uint8_t)bt;
+    c += lit_bytes + 3;
+  } else {
+    c = write_sequence(out, c, in + (size_t)token_start * S, lit_bytes, match_bytes,
+                       offset_bytes, lane);
+  }
+  d_after = token_start + lit + ml;
+}
+
 // Workgroup shape: the hash table (ht_size x u16, 32 KiB for 64 KiB chunks)
 // is the only LDS user and LDS is what limits residency.  The CU allocates
 // LDS in 1280-byte granules, so five separate 32 KiB workgroups do not fit
@@ -243,7 +470,6 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
   constexpr uint32_t LVM = (12 + S - 1) / S; // last valid match, elements
-  constexpr uint32_t MEL = (5 + S - 1) / S;  // min ending literals, elements
   constexpr int INV = 3 / S;                 // lanes without a full 4-byte word
   constexpr int NVMAX = kWave - INV;
 
@@ -280,188 +506,110 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
 
   uint32_t d = 0, c = 0;
   // highest element with 4 readable bytes; windows exist only while
-  // d + LVM < L, so the clamp below is only ever used with L > LVM
+  // d + LVM < L, so the clamped loads are only ever used with L > LVM
   const uint32_t last_word = L > LVM ? L - LVM - 1 : 0;
   // window word of lane t = the 4 bytes at element d+t (reference :848-854;
-  // for every lane < nv none of them is masked).  It is always loaded one
-  // window ahead, unconditionally and with a clamped, always readable index,
-  // so that the compiler can count the loads: a load under a branch would
-  // force s_waitcnt vmcnt(0) at the first use of ANY older load.
+  // for every lane < nv none of them is masked), always loaded one window
+  // ahead.
   uint32_t next = 0;
   if (L > LVM)
     next = load_u32_any(in + (size_t)min((uint32_t)lane, last_word) * S);
+  // the previous window had no match: walk the following ones pipelined
+  bool cold = false;
 
+  uint32_t token_start = 0; // first element not yet written out
   while (d < L) {
-    const uint32_t token_start = d;
-    for (;;) {
-      if (d + LVM >= L) {
-        // literals to the end of the chunk (reference :832-845)
-        c = write_sequence(out, c, in + (size_t)token_start * S,
-                           len - token_start * S, 0, 0, lane);
-        d = L;
-        break;
+    if (cold && (int)(L - d - LVM) >= 2 * NVMAX) {
+      // ---- pipelined walk over match-less full windows (here: a full
+      // window follows this full window).  P's insert is done at once, on
+      // the guess that P has no match; the table half of the following window
+      // N then overlaps P's decision half.  If P does have a match, N is
+      // dropped and the table is put back.
+      Window P;
+      Decision D;
+      {
+        uint32_t pr;
+        window_begin<S, NVMAX>(P, d, next, L, hmask, lane);
+        lds_read_u16_with_bpermute(
+            table + P.hpos, rev_addr4, P.hpos | (P.valid ? 0x80000000u : 0u), P.h_old, pr);
+        window_candidate<S>(P, in, last_word, lane);
+        window_markers<NVMAX>(P, table, pr, rev_lane, perm_addr4, lane);
+        store_insert_image(table, P.pimage);
       }
-      const int nv = min(NVMAX, (int)(L - d - LVM)); // >= 1
-      const uint64_t vmask = lanes_below<NVMAX>(nv);
-      const bool valid = lane < nv;
-      const uint32_t pos = d + (uint32_t)lane;
-      const uint32_t hpos = hash_sum(next) & hmask;
-
-      // LDS round trip 1 of 3.
-      // (B) candidate from earlier windows (reference isValidHash :634-663,
-      // convertIdx :619-632).  The table read needs no mask: hpos is always
-      // inside the table.
-      // (A) in-window duplicates, step 1: my slot and "I am a valid lane" go
-      // to the mirrored lane (see below).
-      uint32_t h_old, pr;
-      lds_read_u16_with_bpermute(
-          table + hpos, rev_addr4, hpos | (valid ? 0x80000000u : 0u), h_old, pr);
-
-      uint32_t cand = (pos & ~0xFFFFu) + h_old;
-      if (cand >= pos)
-        cand -= 65536u;
-      const uint32_t dist = pos - cand;
-      // The reference accepts any candidate within 65535 ELEMENTS and then
-      // truncates the byte offset to 16 bits (:651, :954), which corrupts
-      // typed-mode (S > 1) streams of chunks larger than 64 KiB.  Candidates
-      // whose byte distance does not fit are rejected here; for chunks
-      // <= 64 KiB this never triggers, so those stay bit-identical
-      // (DESIGN.md "deliberate deviations").
-#ifdef HC_ABL_NO_VERIFY
-      const bool probe = false;
-#else
-      const bool probe = valid && h_old != kNullOffset && dist * S <= 65535u;
-#endif
-      // 4-byte verify load, then the speculative load of the next window
-      // (d + nv): the latter is issued AFTER the verify so that waiting for
-      // the verify (in-order vmcnt) does not wait for it
-      const uint32_t cand_word
-          = load_u32_any(in + (size_t)(probe ? cand : min(pos, last_word)) * S);
-      const uint32_t next_pf = load_u32_any(
-          in + (size_t)min(pos + (uint32_t)nv, last_word) * S);
-
-      // What the table insert of a window WITHOUT a match stores (all nv
-      // lanes, reference :958-962), prepared before the match decision so
-      // that its lane permute rides along with round trip 2.  It also puts
-      // back the one marker (below) that this insert does not overwrite.
-      const bool full_insert = nv >= 32; // uniform
-      const uint32_t image
-          = insert_image<NVMAX>(hpos, pos & 0xFFFFu, h_old, nv, lane, true);
-
-      // (A) in-window duplicates: lowest lane holding my word, found through
-      // the hash table itself (no scratch LDS).  Every valid lane posts its
-      // lane id into its own table slot with the lanes in REVERSED order, so
-      // that ds_write_b16's "highest lane wins" leaves the LOWEST window
-      // lane of each slot; reading the slot back names that lane.  If it
-      // holds my word it is exactly min{u : next_u == next_t}; otherwise two
-      // different words share the slot and the lane is settled by the exact
-      // fallback below.  The slots are then put back (h_old) before the real
-      // insert.
-      // LDS round trip 2: markers out, winner of my slot and the permuted
-      // insert image back.
-      lds_lane_exchange_fence();
-      if (pr & 0x80000000u)
-        table[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
-      lds_lane_exchange_fence();
-      const uint32_t w_raw = table[hpos];
-      const uint32_t permuted_image
-          = (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)image);
-      lds_lane_exchange_fence();
-      const uint32_t w = valid ? w_raw : (uint32_t)lane;
-      // LDS round trip 3: the word of that winner
-      const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)next);
-      // masks are combined as scalars: each ballot is one v_cmp.  (An
-      // invalid lane has w == lane, so it can be neither dup nor unresolved.)
-      const uint64_t eqmask = wave_ballot(nw == next);
-      const uint64_t dupmask = eqmask & wave_ballot(w != (uint32_t)lane);
-      const uint64_t unres = vmask & ~eqmask;
-
-      // first lane with an equal lower lane (nv if none) and that lower lane
-      int f = dupmask ? __builtin_ctzll(dupmask) : nv;
-      uint32_t mlane = read_lane(w, f & 63);
-      uint64_t U = unres & lanes_below<NVMAX>(f);
-      if (__builtin_expect(U != 0, 0)) {
-        do {
-          const int u = __builtin_ctzll(U);
-          U &= U - 1;
-          const uint32_t v = read_lane(next, u);
-          const uint64_t m = wave_ballot(next == v) & vmask;
-          const int lo = __builtin_ctzll(m);
-          if (lo != u) {
-            f = u;
-            mlane = (uint32_t)lo;
-            break;
-          }
-        } while (U);
+      for (;;) {
+        Window N;
+        uint32_t prN, nwP;
+        window_begin<S, NVMAX>(N, P.d + (uint32_t)NVMAX, P.next_word, L, hmask, lane);
+        lds_read_u16_with_2bpermutes(
+            table + N.hpos, rev_addr4, N.hpos | (N.valid ? 0x80000000u : 0u),
+            (int)(window_winner(P, lane) * 4u), P.word, N.h_old, prN, nwP);
+        window_candidate<S>(N, in, last_word, lane);
+        window_markers<NVMAX>(N, table, prN, rev_lane, perm_addr4, lane);
+        D = window_decide<NVMAX>(P, nwP, lane);
+        if (D.match) {
+          // N's markers off, then P's insert cut back to its first f lanes
+          if (N.valid)
+            table[N.hpos] = (uint16_t)N.h_old;
+          lds_lane_exchange_fence();
+          break;
+        }
+        store_insert_image(table, N.pimage);
+        P = N;
+        if ((int)(L - P.d - LVM) < 2 * NVMAX) {
+          // no full window behind P: decide P on its own
+          const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
+              (int)(window_winner(P, lane) * 4u), (int)P.word);
+          D = window_decide<NVMAX>(P, nw, lane);
+          break;
+        }
       }
-      // earliest lane (< f) with a verified table candidate wins
-      // (reference :896-923)
-      const uint64_t tmask
-          = wave_ballot(cand_word == next) & wave_ballot(probe) & lanes_below<NVMAX>(f);
-      const bool in_window = f < nv;
-      if (tmask)
-        f = __builtin_ctzll(tmask);
-      const uint32_t tcand = read_lane(cand, f & 63);
-
-      if (tmask != 0 || in_window) {
-        // reference :925-956
-        const uint32_t match_location = tmask ? tcand : d + mlane;
-        // markers off, then the first f lanes go into the table
-        if (valid)
-          table[hpos] = (uint16_t)h_old;
-        lds_lane_exchange_fence();
-        if (f >= 32) {
-          const uint32_t im = insert_image<NVMAX>(hpos, pos & 0xFFFFu, 0, f, lane, false);
-          store_insert_image(table, (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)im));
-        } else {
-          insert_short_window(table, hpos, pos & 0xFFFFu, f, lane);
-        }
-        const uint32_t mpos = d + (uint32_t)f;
-        const uint32_t off_elems = (mpos - match_location) & 0xFFFFu;
-        const uint32_t lit = mpos - token_start;
-        const uint32_t ml
-            = match_length<S>(in, match_location, mpos, L - mpos - MEL, lane);
-
-        // ---- emit (reference writeSequenceData :665-715).  Fast path: the
-        // whole sequence started in this window and is short, so its literal
-        // bytes are the low bytes of the lanes' window words: token, literals
-        // and offset leave as byte stores straight from registers.
-        const uint32_t lit_bytes = lit * S, match_bytes = ml * S;
-        const uint32_t offset_bytes = (off_elems * S) & 0xFFFFu;
-        if (token_start == d && lit_bytes < 15 && match_bytes < 19) {
-          // byte i of the sequence: 0 = token, 1..lit_bytes = literals, then offset lo, hi
-          const uint32_t i = (uint32_t)lane;
-          const uint32_t li = i - 1;                       // literal byte index
-          const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((li / S) * 4u), (int)next);
-          uint32_t bt = (src >> (8u * (li % S))) & 0xFFu;
-          if (i == 0)
-            bt = (lit_bytes << 4) | ((match_bytes - 4u) & 0x0Fu);
-          else if (i == lit_bytes + 1)
-            bt = offset_bytes & 0xFFu;
-          else if (i == lit_bytes + 2)
-            bt = offset_bytes >> 8;
-          if (i < lit_bytes + 3)
-            out[c + i] = (uint8_t)bt;
-          c += lit_bytes + 3;
-        } else {
-          c = write_sequence(out, c, in + (size_t)token_start * S, lit_bytes,
-                             match_bytes, offset_bytes, lane);
-        }
-        d = token_start + lit + ml;
+      if (D.match) {
+        window_insert_first<NVMAX>(P, table, D.f, perm_addr4, lane);
+        emit_match<S>(out, c, in, token_start, P.d, P.word, D, L, lane, d);
         next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
-        break;
+        token_start = d;
+        cold = false;
+        continue;
       }
+      d = P.d + (uint32_t)NVMAX;
+      next = P.next_word;
+      // (at least one more window follows, not a full pair)
+    }
+
+    if (d + LVM >= L) {
+      // literals to the end of the chunk (reference :832-845)
+      c = write_sequence(out, c, in + (size_t)token_start * S,
+                         len - token_start * S, 0, 0, lane);
+      break;
+    }
+    // ---- one window at a time: three LDS round trips, then the decision
+    Window P;
+    uint32_t pr;
+    window_begin<S, NVMAX>(P, d, next, L, hmask, lane);
+    lds_read_u16_with_bpermute(
+        table + P.hpos, rev_addr4, P.hpos | (P.valid ? 0x80000000u : 0u), P.h_old, pr);
+    window_candidate<S>(P, in, last_word, lane, cold);
+    window_markers<NVMAX>(P, table, pr, rev_lane, perm_addr4, lane);
+    const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
+        (int)(window_winner(P, lane) * 4u), (int)P.word);
+    const Decision D = window_decide<NVMAX>(P, nw, lane);
+    if (D.match) {
+      window_insert_first<NVMAX>(P, table, D.f, perm_addr4, lane);
+      emit_match<S>(out, c, in, token_start, P.d, P.word, D, L, lane, d);
+      next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+      token_start = d;
+      cold = false;
+    } else {
       // no match in this window (reference :958-962)
-      if (full_insert) {
-        store_insert_image(table, permuted_image);
+      if (P.nv >= 32) {
+        store_insert_image(table, P.pimage);
       } else {
-        if (valid)
-          table[hpos] = (uint16_t)h_old;
-        lds_lane_exchange_fence();
-        insert_short_window(table, hpos, pos & 0xFFFFu, nv, lane);
+        window_insert_first<NVMAX>(P, table, P.nv, perm_addr4, lane);
       }
-      d += (uint32_t)nv;
-      next = next_pf;
+      d += (uint32_t)P.nv;
+      next = cold ? P.next_word
+                  : load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+      cold = true;
     }
   }
   if (lane == 0)

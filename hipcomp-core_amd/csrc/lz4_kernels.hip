@@ -142,19 +142,26 @@ template <int NVMAX>
 __device__ __forceinline__ uint32_t insert_image(
     uint32_t hpos, uint32_t pos, uint32_t slot_old, int n, int lane, bool restore31)
 {
+  // The rule as lane masks (scalar): lanes 0..30 and 32..n-1 store unless
+  // they share lane 31's slot; lane 63 of a full 64-lane window stores in
+  // any case; lane 31 stores (the old content) only to undo a marker, and
+  // not if lane 63 overwrites that slot anyway.
   const uint32_t h31 = read_lane(hpos, 31);
-  const bool in31 = hpos == h31;
-  // lane 63 takes part only in a full 64-lane window
-  const bool l63_in31 = NVMAX == 64 && n == 64 && read_lane(hpos, 63) == h31;
-  bool store;
-  if (lane < 31)
-    store = !in31;
-  else if (lane == 31)
-    store = restore31 && !l63_in31;
-  else
-    store = lane < n && (!in31 || lane == 63);
+  const uint64_t in31 = wave_ballot(hpos == h31);
+  const uint64_t unless31 = lanes_below<NVMAX>(n) & ~(1ull << 31);
+  uint64_t always = 0;
+  if (NVMAX == 64 && n == 64) {
+    always = 1ull << 63;
+    if (in31 >> 63)
+      restore31 = false;
+  }
+  if (restore31)
+    always |= 1ull << 31;
+  const uint64_t store = always | (unless31 & ~in31);
+  uint32_t flag;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(flag) : "v"(kImageStore), "s"(store));
   const uint32_t value = lane == 31 ? slot_old : pos;
-  return hpos | (store ? kImageStore : 0u) | (value << 16);
+  return hpos | flag | (value << 16);
 }
 
 __device__ __forceinline__ void store_insert_image(uint16_t* table, uint32_t image)
@@ -407,6 +414,45 @@ __device__ __forceinline__ uint32_t match_length(
   return limit;
 }
 
+// One step of the pipelined walk: P has had its table half and its insert, N
+// is the window behind it.  N's table half overlaps P's decision half.
+//   kWalkOn     P had no match, N took P's place (N inserted, undecided)
+//   kWalkMatch  P has the match D; N's markers are off the table again, P's
+//               full insert still has to be cut back (window_insert_first)
+//   kWalkEnd    P had no match and no full window follows N; D is N's decision
+constexpr int kWalkOn = 0, kWalkMatch = 1, kWalkEnd = 2;
+
+template <int S, int NVMAX>
+__device__ __forceinline__ int walk_step(
+    const Window& P, Window& N, Decision& D, uint16_t* table, cgptr in, uint32_t L,
+    uint32_t last_word, uint32_t hmask, uint32_t rev_lane, int rev_addr4, int perm_addr4, int lane)
+{
+  constexpr uint32_t LVM = (12 + S - 1) / S;
+  uint32_t prN, nwP;
+  window_begin<S, NVMAX>(N, P.d + (uint32_t)NVMAX, P.next_word, L, hmask, lane);
+  lds_read_u16_with_2bpermutes(
+      table + N.hpos, rev_addr4, N.hpos | (N.valid ? 0x80000000u : 0u),
+      (int)(window_winner(P, lane) * 4u), P.word, N.h_old, prN, nwP);
+  window_candidate<S>(N, in, last_word, lane);
+  window_markers<NVMAX>(N, table, prN, rev_lane, perm_addr4, lane);
+  D = window_decide<NVMAX>(P, nwP, lane);
+  if (D.match) {
+    if (N.valid)
+      table[N.hpos] = (uint16_t)N.h_old;
+    lds_lane_exchange_fence();
+    return kWalkMatch;
+  }
+  store_insert_image(table, N.pimage);
+  if ((int)(L - N.d - LVM) < 2 * NVMAX) {
+    // no full window behind N: decide N on its own
+    const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
+        (int)(window_winner(N, lane) * 4u), (int)N.word);
+    D = window_decide<NVMAX>(N, nw, lane);
+    return kWalkEnd;
+  }
+  return kWalkOn;
+}
+
 // The sequence that ends with the match D found in the window at element wd
 // (words `word`): literals from token_start, match, offset (reference
 // writeSequenceData :665-715).  Returns the new output cursor in c and the
@@ -525,41 +571,29 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
       // the guess that P has no match; the table half of the following window
       // N then overlaps P's decision half.  If P does have a match, N is
       // dropped and the table is put back.
-      Window P;
+      Window A, B, P;
       Decision D;
       {
         uint32_t pr;
-        window_begin<S, NVMAX>(P, d, next, L, hmask, lane);
+        window_begin<S, NVMAX>(A, d, next, L, hmask, lane);
         lds_read_u16_with_bpermute(
-            table + P.hpos, rev_addr4, P.hpos | (P.valid ? 0x80000000u : 0u), P.h_old, pr);
-        window_candidate<S>(P, in, last_word, lane);
-        window_markers<NVMAX>(P, table, pr, rev_lane, perm_addr4, lane);
-        store_insert_image(table, P.pimage);
+            table + A.hpos, rev_addr4, A.hpos | (A.valid ? 0x80000000u : 0u), A.h_old, pr);
+        window_candidate<S>(A, in, last_word, lane);
+        window_markers<NVMAX>(A, table, pr, rev_lane, perm_addr4, lane);
+        store_insert_image(table, A.pimage);
       }
+      // the two windows in flight swap roles from step to step (no copies)
       for (;;) {
-        Window N;
-        uint32_t prN, nwP;
-        window_begin<S, NVMAX>(N, P.d + (uint32_t)NVMAX, P.next_word, L, hmask, lane);
-        lds_read_u16_with_2bpermutes(
-            table + N.hpos, rev_addr4, N.hpos | (N.valid ? 0x80000000u : 0u),
-            (int)(window_winner(P, lane) * 4u), P.word, N.h_old, prN, nwP);
-        window_candidate<S>(N, in, last_word, lane);
-        window_markers<NVMAX>(N, table, prN, rev_lane, perm_addr4, lane);
-        D = window_decide<NVMAX>(P, nwP, lane);
-        if (D.match) {
-          // N's markers off, then P's insert cut back to its first f lanes
-          if (N.valid)
-            table[N.hpos] = (uint16_t)N.h_old;
-          lds_lane_exchange_fence();
+        int r = walk_step<S, NVMAX>(A, B, D, table, in, L, last_word, hmask, rev_lane,
+                                    rev_addr4, perm_addr4, lane);
+        if (r != kWalkOn) {
+          P = r == kWalkMatch ? A : B;
           break;
         }
-        store_insert_image(table, N.pimage);
-        P = N;
-        if ((int)(L - P.d - LVM) < 2 * NVMAX) {
-          // no full window behind P: decide P on its own
-          const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
-              (int)(window_winner(P, lane) * 4u), (int)P.word);
-          D = window_decide<NVMAX>(P, nw, lane);
+        r = walk_step<S, NVMAX>(B, A, D, table, in, L, last_word, hmask, rev_lane,
+                                rev_addr4, perm_addr4, lane);
+        if (r != kWalkOn) {
+          P = r == kWalkMatch ? B : A;
           break;
         }
       }

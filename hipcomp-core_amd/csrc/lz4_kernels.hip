@@ -190,20 +190,6 @@ __device__ __forceinline__ void lds_read_u16_with_bpermute(
                : "memory");
 }
 
-// Same with a second ds_bpermute in the group (the pipelined walk: the word of
-// the previous window's slot winners travels with the new window's lookup).
-__device__ __forceinline__ void lds_read_u16_with_2bpermutes(
-    const uint16_t* slot, int bp1_addr4, uint32_t bp1_data, int bp2_addr4, uint32_t bp2_data,
-    uint32_t& slot_value, uint32_t& bp1_value, uint32_t& bp2_value)
-{
-  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t*)slot;
-  asm volatile("ds_read_u16 %0, %3\n\tds_bpermute_b32 %1, %4, %5\n\tds_bpermute_b32 %2, %6, %7\n\t"
-               "s_waitcnt lgkmcnt(0)"
-               : "=&v"(slot_value), "=&v"(bp1_value), "=&v"(bp2_value)
-               : "v"(a), "v"(bp1_addr4), "v"(bp1_data), "v"(bp2_addr4), "v"(bp2_data)
-               : "memory");
-}
-
 // ---------------------------------------------------------------------------
 // One window of the match search = 64 consecutive element positions, one per
 // lane (reference :847-962).  Its work comes in two halves:
@@ -357,6 +343,17 @@ __device__ __forceinline__ Decision window_decide(const Window& W, uint32_t nw, 
   return D;
 }
 
+// False only if window_decide would find no match: every valid lane is alone
+// in its slot (then it has no duplicate and nothing is unresolved) and no
+// table candidate holds its lane's word.
+__device__ __forceinline__ bool window_needs_decision(const Window& W, int lane)
+{
+  // (bitwise on purpose: no lazy evaluation, no exec-mask detour)
+  const bool suspect = (window_winner(W, lane) != (uint32_t)lane)
+                       | (W.probe & (W.cand_word == W.word));
+  return wave_ballot(suspect) != 0;
+}
+
 // Table state "only the first f lanes of W were inserted", from any state in
 // which W's slots hold markers or W's full insert.
 template <int NVMAX>
@@ -428,28 +425,38 @@ __device__ __forceinline__ int walk_step(
     uint32_t last_word, uint32_t hmask, uint32_t rev_lane, int rev_addr4, int perm_addr4, int lane)
 {
   constexpr uint32_t LVM = (12 + S - 1) / S;
-  uint32_t prN, nwP;
+  uint32_t prN;
   window_begin<S, NVMAX>(N, P.d + (uint32_t)NVMAX, P.next_word, L, hmask, lane);
-  lds_read_u16_with_2bpermutes(
-      table + N.hpos, rev_addr4, N.hpos | (N.valid ? 0x80000000u : 0u),
-      (int)(window_winner(P, lane) * 4u), P.word, N.h_old, prN, nwP);
+  lds_read_u16_with_bpermute(
+      table + N.hpos, rev_addr4, N.hpos | (N.valid ? 0x80000000u : 0u), N.h_old, prN);
   window_candidate<S>(N, in, last_word, lane);
   window_markers<NVMAX>(N, table, prN, rev_lane, perm_addr4, lane);
-  D = window_decide<NVMAX>(P, nwP, lane);
-  if (D.match) {
-    if (N.valid)
-      table[N.hpos] = (uint16_t)N.h_old;
-    lds_lane_exchange_fence();
-    return kWalkMatch;
+  // Nearly always P has no slot shared by two lanes (so neither a duplicate
+  // nor anything for the exact fallback) and no verified candidate: one test
+  // for all of that (and for "N is the last full window") instead of the
+  // full decision.  A taken branch costs a lone wave ~24 cycles, an untaken
+  // one ~10 (scripts/probes/branch_cost.hip).
+  const bool last = (int)(L - N.d - LVM) < 2 * NVMAX;
+  if (__builtin_expect(window_needs_decision(P, lane) | last, 0)) {
+    const uint32_t nwP = (uint32_t)__builtin_amdgcn_ds_bpermute(
+        (int)(window_winner(P, lane) * 4u), (int)P.word);
+    D = window_decide<NVMAX>(P, nwP, lane);
+    if (D.match) {
+      if (N.valid)
+        table[N.hpos] = (uint16_t)N.h_old;
+      lds_lane_exchange_fence();
+      return kWalkMatch;
+    }
+    if (last) {
+      // no full window behind N: decide N on its own
+      store_insert_image(table, N.pimage);
+      const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
+          (int)(window_winner(N, lane) * 4u), (int)N.word);
+      D = window_decide<NVMAX>(N, nw, lane);
+      return kWalkEnd;
+    }
   }
   store_insert_image(table, N.pimage);
-  if ((int)(L - N.d - LVM) < 2 * NVMAX) {
-    // no full window behind N: decide N on its own
-    const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
-        (int)(window_winner(N, lane) * 4u), (int)N.word);
-    D = window_decide<NVMAX>(N, nw, lane);
-    return kWalkEnd;
-  }
   return kWalkOn;
 }
 

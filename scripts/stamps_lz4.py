@@ -14,8 +14,8 @@ f = lib._dll.hipcompBatchedLZ4DebugStamps
 f.argtypes = [ctypes.c_void_p]
 assert f(out) == 0
 v = list(out)[:8]; tot = sum(v)
-names = ["0 window wait+hash", "1 table read + mirror bperm", "2 issue loads, marker, readback", "3 word bperm, ballots, dup decision",
-         "4 verify wait + table decision", "5 insert", "6 rest (final literals / match path)", "7"]
+names = ["0 wait words+verify, hash", "1 LDS round trip 1", "2 candidate, loads, markers (+LDS wait)", "3 decision",
+         "4 insert", "5 between steps", "6 everything outside the walk", "7"]
 print(dist, dtype, "total Gcycles", tot / 1e9)
 for n, x in zip(names, v):
-    print(f"  {n:40s} {100 * x / tot:5.1f} %")
+    print(f"  {n:44s} {100 * x / tot:5.1f} %   {x / (5000 * (1032 if dtype == 'char' else 258)):7.1f} ticks/window")

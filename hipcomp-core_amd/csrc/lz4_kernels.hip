@@ -209,7 +209,8 @@ struct Window
   uint32_t cand;      // element the slot points to
   bool probe;         // the candidate is usable: verify its word
   uint32_t cand_word; // 4 bytes at cand (in flight until first use)
-  uint32_t next_word; // 4 bytes at element d + nv + lane (in flight)
+  uint32_t next_word; // 4 bytes at element d + nv + lane, in the pipelined walk
+                      // at d + 2 nv + lane (in flight)
   uint32_t w_raw;     // marker read back from my slot: lowest lane in it
   uint32_t pimage;    // lane-permuted insert image of the whole window
 };
@@ -240,7 +241,7 @@ __device__ __forceinline__ void window_begin(
 // with a clamped, always readable index so that the compiler can count them.
 template <int S>
 __device__ __forceinline__ void window_candidate(
-    Window& W, cgptr in, uint32_t last_word, int lane, bool load_next = true)
+    Window& W, cgptr in, uint32_t last_word, int lane, bool load_next = true, int ahead = 1)
 {
   const uint32_t pos = W.d + (uint32_t)lane;
   uint32_t cand = (pos & ~0xFFFFu) + W.h_old;
@@ -262,8 +263,10 @@ __device__ __forceinline__ void window_candidate(
   // (not after a window with a match: this one most likely has one too, the
   // words would be dropped, and a load in flight into a register the match
   // path wants to reuse makes that path wait for it)
+  // (the pipelined walk loads two windows ahead: one step of it is shorter
+  // than a trip to HBM)
   if (load_next)
-    W.next_word = load_u32_any(in + (size_t)min(pos + (uint32_t)W.nv, last_word) * S);
+    W.next_word = load_u32_any(in + (size_t)min(pos + (uint32_t)(ahead * W.nv), last_word) * S);
 }
 
 // (A) in-window duplicates: lowest lane holding my word, found through the
@@ -421,15 +424,18 @@ constexpr int kWalkOn = 0, kWalkMatch = 1, kWalkEnd = 2;
 
 template <int S, int NVMAX>
 __device__ __forceinline__ int walk_step(
-    const Window& P, Window& N, Decision& D, uint16_t* table, cgptr in, uint32_t L,
-    uint32_t last_word, uint32_t hmask, uint32_t rev_lane, int rev_addr4, int perm_addr4, int lane)
+    const Window& P, Window& N, uint32_t& words_behind, Decision& D, uint16_t* table, cgptr in,
+    uint32_t L, uint32_t last_word, uint32_t hmask, uint32_t rev_lane, int rev_addr4,
+    int perm_addr4, int lane)
 {
   constexpr uint32_t LVM = (12 + S - 1) / S;
   uint32_t prN;
-  window_begin<S, NVMAX>(N, P.d + (uint32_t)NVMAX, P.next_word, L, hmask, lane);
+  // words_behind: the words of the window behind the newest one
+  window_begin<S, NVMAX>(N, P.d + (uint32_t)NVMAX, words_behind, L, hmask, lane);
+  words_behind = P.next_word;
   lds_read_u16_with_bpermute(
       table + N.hpos, rev_addr4, N.hpos | (N.valid ? 0x80000000u : 0u), N.h_old, prN);
-  window_candidate<S>(N, in, last_word, lane);
+  window_candidate<S>(N, in, last_word, lane, true, 2);
   window_markers<NVMAX>(N, table, prN, rev_lane, perm_addr4, lane);
   // Nearly always P has no slot shared by two lanes (so neither a duplicate
   // nor anything for the exact fallback) and no verified candidate: one test
@@ -580,25 +586,27 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
       // dropped and the table is put back.
       Window A, B, P;
       Decision D;
+      uint32_t words_behind = load_u32_any(
+          in + (size_t)min(d + (uint32_t)(NVMAX + lane), last_word) * S);
       {
         uint32_t pr;
         window_begin<S, NVMAX>(A, d, next, L, hmask, lane);
         lds_read_u16_with_bpermute(
             table + A.hpos, rev_addr4, A.hpos | (A.valid ? 0x80000000u : 0u), A.h_old, pr);
-        window_candidate<S>(A, in, last_word, lane);
+        window_candidate<S>(A, in, last_word, lane, true, 2);
         window_markers<NVMAX>(A, table, pr, rev_lane, perm_addr4, lane);
         store_insert_image(table, A.pimage);
       }
       // the two windows in flight swap roles from step to step (no copies)
       for (;;) {
-        int r = walk_step<S, NVMAX>(A, B, D, table, in, L, last_word, hmask, rev_lane,
-                                    rev_addr4, perm_addr4, lane);
+        int r = walk_step<S, NVMAX>(A, B, words_behind, D, table, in, L, last_word, hmask,
+                                    rev_lane, rev_addr4, perm_addr4, lane);
         if (r != kWalkOn) {
           P = r == kWalkMatch ? A : B;
           break;
         }
-        r = walk_step<S, NVMAX>(B, A, D, table, in, L, last_word, hmask, rev_lane,
-                                rev_addr4, perm_addr4, lane);
+        r = walk_step<S, NVMAX>(B, A, words_behind, D, table, in, L, last_word, hmask,
+                                rev_lane, rev_addr4, perm_addr4, lane);
         if (r != kWalkOn) {
           P = r == kWalkMatch ? B : A;
           break;
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
         continue;
       }
       d = P.d + (uint32_t)NVMAX;
-      next = P.next_word;
+      next = words_behind;
       // (at least one more window follows, not a full pair)
     }
 

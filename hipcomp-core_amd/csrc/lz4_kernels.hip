@@ -207,7 +207,7 @@ struct Window
   uint32_t hpos;      // my table slot
   uint32_t h_old;     // what the slot held before this window
   uint32_t cand;      // element the slot points to
-  bool probe;         // the candidate is usable: verify its word
+  uint64_t probe;     // lanes whose candidate is usable: its word gets verified (uniform)
   uint32_t cand_word; // 4 bytes at cand (in flight until first use)
   uint32_t next_word; // 4 bytes at element d + nv + lane, in the pipelined walk
                       // at d + 2 nv + lane (in flight)
@@ -222,13 +222,14 @@ struct Decision
   uint32_t match_location; // element it matches
 };
 
-template <int S, int NVMAX>
+// FULL: the caller knows that the window has all NVMAX lanes.
+template <int S, int NVMAX, bool FULL = false>
 __device__ __forceinline__ void window_begin(
     Window& W, uint32_t d, uint32_t word, uint32_t L, uint32_t hmask, int lane)
 {
   constexpr uint32_t LVM = (12 + S - 1) / S;
   W.d = d;
-  W.nv = min(NVMAX, (int)(L - d - LVM)); // >= 1
+  W.nv = FULL ? NVMAX : min(NVMAX, (int)(L - d - LVM)); // >= 1
   W.valid = lane < W.nv;
   W.word = word;
   W.hpos = hash_sum(word) & hmask;
@@ -239,14 +240,17 @@ __device__ __forceinline__ void window_begin(
 // window's words: the latter is issued AFTER the verify so that waiting for the
 // verify (in-order vmcnt) does not wait for it.  Both loads are unconditional
 // with a clamped, always readable index so that the compiler can count them.
-template <int S>
+// FULL: a full window follows this one, so every lane's own position is a
+// readable word and needs no clamp.
+template <int S, bool FULL = false>
 __device__ __forceinline__ void window_candidate(
     Window& W, cgptr in, uint32_t last_word, int lane, bool load_next = true, int ahead = 1)
 {
   const uint32_t pos = W.d + (uint32_t)lane;
-  uint32_t cand = (pos & ~0xFFFFu) + W.h_old;
-  if (cand >= pos)
-    cand -= 65536u;
+  // The slot holds the low 16 bits of an element before pos: the candidate
+  // is the nearest such element, 1..65536 elements back.
+  const uint32_t back = (pos - 1u - W.h_old) & 0xFFFFu; // distance - 1
+  const uint32_t cand = pos - 1u - back;
   // The reference accepts any candidate within 65535 ELEMENTS and then
   // truncates the byte offset to 16 bits (:651, :954), which corrupts
   // typed-mode (S > 1) streams of chunks larger than 64 KiB.  Candidates
@@ -254,17 +258,19 @@ __device__ __forceinline__ void window_candidate(
   // <= 64 KiB this never triggers, so those stay bit-identical
   // (DESIGN.md "deliberate deviations").
 #ifdef HC_ABL_NO_VERIFY
-  W.probe = false;
+  const bool probe = false;
 #else
-  W.probe = W.valid && W.h_old != kNullOffset && (pos - cand) * S <= 65535u;
+  const bool probe = W.valid & (W.h_old != kNullOffset) & (back < 65535u / S);
 #endif
+  W.probe = wave_ballot(probe);
   W.cand = cand;
-  W.cand_word = load_u32_any(in + (size_t)(W.probe ? cand : min(pos, last_word)) * S);
-  // (not after a window with a match: this one most likely has one too, the
-  // words would be dropped, and a load in flight into a register the match
-  // path wants to reuse makes that path wait for it)
-  // (the pipelined walk loads two windows ahead: one step of it is shorter
-  // than a trip to HBM)
+  const uint32_t own = FULL ? pos : min(pos, last_word);
+  W.cand_word = load_u32_any(in + (size_t)(probe ? cand : own) * S);
+  // Next words: not after a window with a match (this one most likely has
+  // one too, the words would be dropped, and a load in flight into a
+  // register the match path wants to reuse makes that path wait for it).
+  // The pipelined walk loads two windows ahead: one step of it is shorter
+  // than a trip to HBM.
   if (load_next)
     W.next_word = load_u32_any(in + (size_t)min(pos + (uint32_t)(ahead * W.nv), last_word) * S);
 }
@@ -334,7 +340,7 @@ __device__ __forceinline__ Decision window_decide(const Window& W, uint32_t nw, 
   // earliest lane (< f) with a verified table candidate wins
   // (reference :896-923)
   const uint64_t tmask
-      = wave_ballot(W.cand_word == W.word) & wave_ballot(W.probe) & lanes_below<NVMAX>(f);
+      = wave_ballot(W.cand_word == W.word) & W.probe & lanes_below<NVMAX>(f);
   const bool in_window = f < W.nv;
   if (tmask)
     f = __builtin_ctzll(tmask);
@@ -351,10 +357,9 @@ __device__ __forceinline__ Decision window_decide(const Window& W, uint32_t nw, 
 // table candidate holds its lane's word.
 __device__ __forceinline__ bool window_needs_decision(const Window& W, int lane)
 {
-  // (bitwise on purpose: no lazy evaluation, no exec-mask detour)
-  const bool suspect = (window_winner(W, lane) != (uint32_t)lane)
-                       | (W.probe & (W.cand_word == W.word));
-  return wave_ballot(suspect) != 0;
+  return (wave_ballot(window_winner(W, lane) != (uint32_t)lane)
+          | (wave_ballot(W.cand_word == W.word) & W.probe))
+         != 0;
 }
 
 // Table state "only the first f lanes of W were inserted", from any state in
@@ -431,11 +436,11 @@ __device__ __forceinline__ int walk_step(
   constexpr uint32_t LVM = (12 + S - 1) / S;
   uint32_t prN;
   // words_behind: the words of the window behind the newest one
-  window_begin<S, NVMAX>(N, P.d + (uint32_t)NVMAX, words_behind, L, hmask, lane);
+  window_begin<S, NVMAX, true>(N, P.d + (uint32_t)NVMAX, words_behind, L, hmask, lane);
   words_behind = P.next_word;
   lds_read_u16_with_bpermute(
       table + N.hpos, rev_addr4, N.hpos | (N.valid ? 0x80000000u : 0u), N.h_old, prN);
-  window_candidate<S>(N, in, last_word, lane, true, 2);
+  window_candidate<S, true>(N, in, last_word, lane, true, 2);
   window_markers<NVMAX>(N, table, prN, rev_lane, perm_addr4, lane);
   // Nearly always P has no slot shared by two lanes (so neither a duplicate
   // nor anything for the exact fallback) and no verified candidate: one test
@@ -590,10 +595,10 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
           in + (size_t)min(d + (uint32_t)(NVMAX + lane), last_word) * S);
       {
         uint32_t pr;
-        window_begin<S, NVMAX>(A, d, next, L, hmask, lane);
+        window_begin<S, NVMAX, true>(A, d, next, L, hmask, lane);
         lds_read_u16_with_bpermute(
             table + A.hpos, rev_addr4, A.hpos | (A.valid ? 0x80000000u : 0u), A.h_old, pr);
-        window_candidate<S>(A, in, last_word, lane, true, 2);
+        window_candidate<S, true>(A, in, last_word, lane, true, 2);
         window_markers<NVMAX>(A, table, pr, rev_lane, perm_addr4, lane);
         store_insert_image(table, A.pimage);
       }

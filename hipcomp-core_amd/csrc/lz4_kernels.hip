@@ -696,6 +696,19 @@ __device__ __forceinline__ bool read_lsic(
   return true;
 }
 
+// Bytes the decoder's fast path may touch from the token on: token, up to 14
+// literals, 2 offset bytes.
+constexpr uint32_t kFastSeqBytes = 17;
+
+// 4 bytes at byte index idx (< 252) of the register window `win` (lane t =
+// dword at byte 4t); idx is wave-uniform, the result a scalar.
+__device__ __forceinline__ uint32_t window_bytes(uint32_t win, uint32_t idx)
+{
+  const uint32_t q = idx >> 2;
+  const uint32_t lo = read_lane(win, (int)q), hi = read_lane(win, (int)q + 1);
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> ((idx & 3u) * 8u));
+}
+
 template <bool WRITE_OUT>
 __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_kernel(
     const uint8_t* const* __restrict__ comp_ptrs,
@@ -719,7 +732,54 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
 
   uint32_t c = 0, d = 0;
   bool corrupt = false;
+  // 256 bytes of the compressed stream in registers: lane t holds the dword
+  // at stream index win_base + 4t (any alignment).  Short sequences are
+  // parsed from it with v_readlane, i.e. without a memory round trip in the
+  // chain that leads from one token to the next.
+  uint32_t win = 0, win_base = 0;
+  bool have_win = false;
   while (c < end) {
+    // ---- fast path: token + up to 14 literals + offset inside the stream,
+    // short non-overlapping match.  Anything else takes the general path below.
+    if (c + kFastSeqBytes <= end) {
+      if (!have_win || c - win_base > 256u - 8u - kFastSeqBytes) {
+        // (end >= kFastSeqBytes here, so end - 4 is a readable dword index)
+        win_base = c;
+        win = load_u32_any(comp + min(c + 4u * (uint32_t)lane, end - 4u));
+        // wait here: left to the compiler the wait lands after the branch,
+        // where it also waits for the previous sequence's store every time
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+        have_win = true;
+      }
+      const uint32_t idx = c - win_base;
+      const uint32_t t = window_bytes(win, idx);
+      const uint32_t tokf = t & 0xFFu;
+      const uint32_t litf = tokf >> 4, mlf = (tokf & 15u) + 4u;
+      const uint32_t off = window_bytes(win, idx + 1u + litf) & 0xFFFFu;
+      // literal run and match lengths in the token itself, output fits,
+      // offset inside what exists, source and destination do not overlap
+      const bool fast = (litf < 15u) & (mlf < 19u) & (d + litf + mlf <= cap) & (off != 0u)
+                        & (off <= d + litf) & (off >= mlf);
+      if (fast) {
+        if (WRITE_OUT) {
+          // One byte per lane for literals AND match: lane i < lit copies
+          // literal i; lane lit + j copies match byte j, whose source is the
+          // output `off` bytes back -- or, if that lies inside this
+          // sequence's own literals, the same byte in the compressed stream
+          // (no store -> load round trip on out[]).  Earlier stores of this
+          // wave to out[] are ordered before these loads (one wave, in-order
+          // vector memory, one L1).
+          const uint32_t i = (uint32_t)lane;
+          const int32_t a = (int32_t)(i - (i < litf ? 0u : off)); // index relative to d
+          cgptr src = a >= 0 ? comp + (c + 1u + (uint32_t)a) : static_cast<cgptr>(out + d) + a;
+          if (i < litf + mlf)
+            out[d + i] = *src;
+        }
+        c += 1u + litf + 2u;
+        d += litf + mlf;
+        continue;
+      }
+    }
     const uint32_t tok = uniform((uint32_t)comp[c++]);
     uint32_t lit = tok >> 4;
     if (lit == 15 && !read_lsic(comp, c, end, lit)) {

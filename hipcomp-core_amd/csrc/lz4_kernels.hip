@@ -739,6 +739,8 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
   uint32_t win = 0, win_base = 0;
   bool have_win = false;
   while (c < end) {
+    uint32_t tok = 0;
+    bool tok_known = false;
     // ---- fast path: token + up to 14 literals + offset inside the stream,
     // short non-overlapping match.  Anything else takes the general path below.
     if (c + kFastSeqBytes <= end) {
@@ -752,35 +754,45 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
         have_win = true;
       }
       const uint32_t idx = c - win_base;
-      const uint32_t t = window_bytes(win, idx);
-      const uint32_t tokf = t & 0xFFu;
-      const uint32_t litf = tokf >> 4, mlf = (tokf & 15u) + 4u;
-      const uint32_t off = window_bytes(win, idx + 1u + litf) & 0xFFFFu;
-      // literal run and match lengths in the token itself, output fits,
-      // offset inside what exists, source and destination do not overlap
-      const bool fast = (litf < 15u) & (mlf < 19u) & (d + litf + mlf <= cap) & (off != 0u)
-                        & (off <= d + litf) & (off >= mlf);
-      if (fast) {
-        if (WRITE_OUT) {
-          // One byte per lane for literals AND match: lane i < lit copies
-          // literal i; lane lit + j copies match byte j, whose source is the
-          // output `off` bytes back -- or, if that lies inside this
-          // sequence's own literals, the same byte in the compressed stream
-          // (no store -> load round trip on out[]).  Earlier stores of this
-          // wave to out[] are ordered before these loads (one wave, in-order
-          // vector memory, one L1).
-          const uint32_t i = (uint32_t)lane;
-          const int32_t a = (int32_t)(i - (i < litf ? 0u : off)); // index relative to d
-          cgptr src = a >= 0 ? comp + (c + 1u + (uint32_t)a) : static_cast<cgptr>(out + d) + a;
-          if (i < litf + mlf)
-            out[d + i] = *src;
+      tok = window_bytes(win, idx) & 0xFFu;
+      tok_known = true;
+      const uint32_t litf = tok >> 4, mlf = (tok & 15u) + 4u;
+      if ((litf < 15u) & (mlf < 19u)) { // both lengths in the token itself
+        const uint32_t off = window_bytes(win, idx + 1u + litf) & 0xFFFFu;
+        // output fits, offset inside what exists, source and destination do
+        // not overlap
+        if ((d + litf + mlf <= cap) & (off != 0u) & (off <= d + litf) & (off >= mlf)) {
+          if (WRITE_OUT) {
+            // One byte per lane for literals AND match: lane i < lit carries
+            // literal i, lane lit + j match byte j.  `a` is the source as an
+            // index relative to d: >= 0 means a literal of this very
+            // sequence, i.e. a byte of the stream window (for match bytes
+            // too: no round trip through the output); < 0 means earlier
+            // output.
+            const uint32_t i = (uint32_t)lane;
+            const int32_t a = (int32_t)(i - (i < litf ? 0u : off));
+            const uint32_t sidx = idx + 1u + (uint32_t)max(a, 0);
+            const uint32_t sw = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                (int)((sidx >> 2) * 4u), (int)win);
+            uint32_t byte = sw >> ((sidx & 3u) * 8u);
+            if (off > litf) { // some match bytes come from earlier output
+              // Earlier stores of this wave to out[] are ordered before this
+              // load (one wave, in-order vector memory, one L1).
+              const uint32_t gb = *(static_cast<cgptr>(out + d) + min(a, -1));
+              byte = a >= 0 ? byte : gb;
+            }
+            if (i < litf + mlf)
+              out[d + i] = (uint8_t)byte;
+          }
+          c += 1u + litf + 2u;
+          d += litf + mlf;
+          continue;
         }
-        c += 1u + litf + 2u;
-        d += litf + mlf;
-        continue;
       }
     }
-    const uint32_t tok = uniform((uint32_t)comp[c++]);
+    if (!tok_known)
+      tok = uniform((uint32_t)comp[c]);
+    ++c;
     uint32_t lit = tok >> 4;
     if (lit == 15 && !read_lsic(comp, c, end, lit)) {
       corrupt = true;

@@ -700,15 +700,6 @@ __device__ __forceinline__ bool read_lsic(
 // literals, 2 offset bytes.
 constexpr uint32_t kFastSeqBytes = 17;
 
-// 4 bytes at byte index idx (< 252) of the register window `win` (lane t =
-// dword at byte 4t); idx is wave-uniform, the result a scalar.
-__device__ __forceinline__ uint32_t window_bytes(uint32_t win, uint32_t idx)
-{
-  const uint32_t q = idx >> 2;
-  const uint32_t lo = read_lane(win, (int)q), hi = read_lane(win, (int)q + 1);
-  return (uint32_t)((((uint64_t)hi << 32) | lo) >> ((idx & 3u) * 8u));
-}
-
 template <bool WRITE_OUT>
 __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_kernel(
     const uint8_t* const* __restrict__ comp_ptrs,
@@ -732,33 +723,23 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
 
   uint32_t c = 0, d = 0;
   bool corrupt = false;
-  // 256 bytes of the compressed stream in registers: lane t holds the dword
-  // at stream index win_base + 4t (any alignment).  Short sequences are
-  // parsed from it with v_readlane, i.e. without a memory round trip in the
-  // chain that leads from one token to the next.
-  uint32_t win = 0, win_base = 0;
-  bool have_win = false;
+  // Short sequences are parsed from a register window of the stream
+  // (StreamWindow), i.e. without a memory round trip in the chain that leads
+  // from one token to the next.
+  StreamWindow sw;
   while (c < end) {
     uint32_t tok = 0;
     bool tok_known = false;
     // ---- fast path: token + up to 14 literals + offset inside the stream,
     // short non-overlapping match.  Anything else takes the general path below.
     if (c + kFastSeqBytes <= end) {
-      if (!have_win || c - win_base > 256u - 8u - kFastSeqBytes) {
-        // (end >= kFastSeqBytes here, so end - 4 is a readable dword index)
-        win_base = c;
-        win = load_u32_any(comp + min(c + 4u * (uint32_t)lane, end - 4u));
-        // wait here: left to the compiler the wait lands after the branch,
-        // where it also waits for the previous sequence's store every time
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-        have_win = true;
-      }
-      const uint32_t idx = c - win_base;
-      tok = window_bytes(win, idx) & 0xFFu;
+      sw.ensure(comp, c, end, kFastSeqBytes, lane);
+      const uint32_t idx = c - sw.base;
+      tok = sw.bytes_at(idx) & 0xFFu;
       tok_known = true;
       const uint32_t litf = tok >> 4, mlf = (tok & 15u) + 4u;
       if ((litf < 15u) & (mlf < 19u)) { // both lengths in the token itself
-        const uint32_t off = window_bytes(win, idx + 1u + litf) & 0xFFFFu;
+        const uint32_t off = sw.bytes_at(idx + 1u + litf) & 0xFFFFu;
         // output fits, offset inside what exists, source and destination do
         // not overlap
         if ((d + litf + mlf <= cap) & (off != 0u) & (off <= d + litf) & (off >= mlf)) {
@@ -772,9 +753,9 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
             const uint32_t i = (uint32_t)lane;
             const int32_t a = (int32_t)(i - (i < litf ? 0u : off));
             const uint32_t sidx = idx + 1u + (uint32_t)max(a, 0);
-            const uint32_t sw = (uint32_t)__builtin_amdgcn_ds_bpermute(
-                (int)((sidx >> 2) * 4u), (int)win);
-            uint32_t byte = sw >> ((sidx & 3u) * 8u);
+            const uint32_t sword = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                (int)((sidx >> 2) * 4u), (int)sw.words);
+            uint32_t byte = sword >> ((sidx & 3u) * 8u);
             if (off > litf) { // some match bytes come from earlier output
               // Earlier stores of this wave to out[] are ordered before this
               // load (one wave, in-order vector memory, one L1).

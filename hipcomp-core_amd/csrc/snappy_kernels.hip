@@ -271,6 +271,10 @@ __global__ __launch_bounds__(256) void snappy_get_sizes_kernel(
 
 constexpr int kDecompWavesPerBlock = 4;
 
+// How far past an element's tag the decoder looks in the register window
+// before it asks for the window again (the tag and 3 bytes behind it).
+constexpr uint32_t kSnappyWindowReach = 4;
+
 __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompress_kernel(
     const uint8_t* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes,
@@ -307,17 +311,31 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
     } else {
       bytes_left = usize;
       uint32_t dst_pos = 0;
+      StreamWindow sw;
       while (bytes_left > 0) {
         if (cur >= end)
           break;
-        // tag byte plus the four bytes behind it (clamped to the stream), uniform
-        const uint32_t b0 = uniform((uint32_t)comp[cur]);
+        // Tag byte and the three bytes behind it, wave-uniform: from the
+        // register window of the stream (no memory round trip in the chain
+        // from one element to the next), near the end of the stream from
+        // memory.  Bytes past the end read as 0; every use is guarded by a
+        // length check.
+        uint32_t t;
+        if (end - cur >= kSnappyWindowReach) {
+          sw.ensure(comp, cur, end, kSnappyWindowReach, lane);
+          t = sw.bytes_at(cur - sw.base);
+        } else {
+          t = uniform((uint32_t)comp[cur]);
+          for (uint32_t i = 1; i < 4 && cur + i < end; ++i)
+            t |= uniform((uint32_t)comp[cur + i]) << (8 * i);
+        }
+        const uint32_t b0 = t & 0xFFu;
         uint32_t blen, offset;
         if (b0 & 3u) {
           if (!(b0 & 2u)) { // xxxxxx01.oooooooo
             if (end - cur < 2)
               break;
-            offset = ((b0 & 0xe0u) << 3) | uniform((uint32_t)comp[cur + 1]);
+            offset = ((b0 & 0xe0u) << 3) | ((t >> 8) & 0xFFu);
             blen = ((b0 >> 2) & 7u) + 4u;
             cur += 2;
           } else if (b0 & 1u) { // 4-byte offset
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
           } else { // 2-byte offset
             if (end - cur < 3)
               break;
-            offset = uniform((uint32_t)comp[cur + 1] | ((uint32_t)comp[cur + 2] << 8));
+            offset = (t >> 8) & 0xFFFFu;
             blen = (b0 >> 2) + 1u;
             cur += 3;
           }

@@ -187,4 +187,46 @@ __device__ __forceinline__ void wave_copy(
     dst[(nvec << 4) + lane] = src[(nvec << 4) + lane];
 }
 
+// ---------------------------------------------------------------------------
+// 256 bytes of a byte stream in registers: lane t holds the dword at stream
+// index base + 4t (any alignment).  A decoder reads its tags / tokens /
+// offsets from it with v_readlane instead of taking a memory round trip for
+// each of them.
+// ---------------------------------------------------------------------------
+struct StreamWindow
+{
+  uint32_t words = 0; // per lane
+  uint32_t base = 0;  // stream index of lane 0's dword (wave-uniform)
+  bool valid = false;
+
+  // Makes the window cover [pos, pos + reach + 8).  Needs pos < end, end >= 4
+  // and reach <= 64: `reach` is how far past pos the caller will ask for bytes
+  // before calling ensure() the next time.
+  __device__ __forceinline__ void ensure(cgptr stream, uint32_t pos, uint32_t end, uint32_t reach, int lane)
+  {
+    if (!valid || pos - base > 256u - 8u - reach) {
+      base = pos;
+      // Lanes whose dword would reach past the end of the stream load the
+      // last dword of the stream instead (end >= 4 here) and shift it into
+      // place: bytes past the end read as 0.
+      const uint32_t at = pos + 4u * (uint32_t)lane;
+      const uint32_t over = at > end - 4u ? at - (end - 4u) : 0u; // bytes
+      const uint32_t raw = load_u32_any(stream + (at - over));
+      words = over >= 4u ? 0u : raw >> (8u * over);
+      // wait here: left to the compiler the wait lands after the branch, where
+      // it would also wait for the caller's last store every time
+      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+      valid = true;
+    }
+  }
+
+  // 4 bytes at byte index idx (< 252) of the window; idx is wave-uniform.
+  __device__ __forceinline__ uint32_t bytes_at(uint32_t idx) const
+  {
+    const uint32_t q = idx >> 2;
+    const uint32_t lo = read_lane(words, (int)q), hi = read_lane(words, (int)q + 1);
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> ((idx & 3u) * 8u));
+  }
+};
+
 } // namespace hcamd

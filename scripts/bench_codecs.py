@@ -17,11 +17,15 @@ ap.add_argument("--chunks", type=int, default=20000)
 ap.add_argument("--codec", default="both")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--no-ref", action="store_true")
+ap.add_argument("--extra-lib", action="append", default=[], help="name=path of another build of this library to time next to it")
 a = ap.parse_args()
 hc = importlib.import_module("hipcomp-core_amd")
 from oracle import oracle as O
 dev = torch.device("cuda:0")
 libs = [("ours", hc.default_library())]
+for spec in a.extra_lib:
+    nm, path = spec.split("=", 1)
+    libs.append((nm, hc.HipcompLibrary(path if os.path.isabs(path) else os.path.join(ROOT, path))))
 if not a.no_ref and os.path.exists(O.REF_LIB_PATH):
     libs.append(("reference", hc.HipcompLibrary(O.REF_LIB_PATH)))
 

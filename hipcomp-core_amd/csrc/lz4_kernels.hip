@@ -287,18 +287,21 @@ __device__ __forceinline__ void window_candidate(
 // window WITHOUT a match (all nv lanes, reference :958-962); storing that image
 // overwrites every marker but the one of lane 31's slot, whose old content the
 // image carries (insert_image).  Nothing is waited for here.
-template <int NVMAX>
+template <int NVMAX, bool WITH_IMAGE = true>
 __device__ __forceinline__ void window_markers(
     Window& W, uint16_t* table, uint32_t pr, uint32_t rev_lane, int perm_addr4, int lane)
 {
-  const uint32_t image = insert_image<NVMAX>(
-      W.hpos, (W.d + (uint32_t)lane) & 0xFFFFu, W.h_old, W.nv, lane, true);
+  uint32_t image = 0;
+  if (WITH_IMAGE)
+    image = insert_image<NVMAX>(
+        W.hpos, (W.d + (uint32_t)lane) & 0xFFFFu, W.h_old, W.nv, lane, true);
   lds_lane_exchange_fence();
   if (pr & 0x80000000u)
     table[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
   lds_lane_exchange_fence();
   W.w_raw = table[W.hpos];
-  W.pimage = (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)image);
+  if (WITH_IMAGE)
+    W.pimage = (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)image);
   lds_lane_exchange_fence();
 }
 
@@ -643,7 +646,9 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
     lds_read_u16_with_bpermute(
         table + P.hpos, rev_addr4, P.hpos | (P.valid ? 0x80000000u : 0u), P.h_old, pr);
     window_candidate<S>(P, in, last_word, lane, cold);
-    window_markers<NVMAX>(P, table, pr, rev_lane, perm_addr4, lane);
+    // (no insert image yet: after a window with a match this one most likely
+    // has one too and would not use it)
+    window_markers<NVMAX, false>(P, table, pr, rev_lane, perm_addr4, lane);
     const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
         (int)(window_winner(P, lane) * 4u), (int)P.word);
     const Decision D = window_decide<NVMAX>(P, nw, lane);
@@ -654,12 +659,8 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
       token_start = d;
       cold = false;
     } else {
-      // no match in this window (reference :958-962)
-      if (P.nv >= 32) {
-        store_insert_image(table, P.pimage);
-      } else {
-        window_insert_first<NVMAX>(P, table, P.nv, perm_addr4, lane);
-      }
+      // no match in this window (reference :958-962): all nv lanes go in
+      window_insert_first<NVMAX>(P, table, P.nv, perm_addr4, lane);
       d += (uint32_t)P.nv;
       next = cold ? P.next_word
                   : load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);

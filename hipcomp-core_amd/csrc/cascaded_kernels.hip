@@ -36,7 +36,10 @@ namespace {
 
 constexpr uint32_t kChunkBytes = 4096;
 constexpr uint32_t kPartMeta = 8;
-constexpr int kWavesPerBlock = 4;
+#ifndef HC_CASC_WAVES
+#define HC_CASC_WAVES 1 // 10 KiB of LDS per wave: separate blocks pack 14 per CU, 4-wave blocks only 12
+#endif
+constexpr int kWavesPerBlock = HC_CASC_WAVES;
 
 template <int S> struct UIntOf;
 template <> struct UIntOf<1> { typedef uint8_t type; typedef int8_t stype; };
@@ -51,8 +54,9 @@ __host__ __device__ constexpr uint32_t elem_buf_bytes() { return kChunkBytes + 1
 template <int S>
 __host__ __device__ constexpr uint32_t wave_lds_bytes()
 {
-  // encoder: two element buffers + run-count array + 64-byte metadata image
-  return 2 * elem_buf_bytes() + (kChunkBytes / S) * 2 + 64;
+  // encoder: one element buffer (every layer works in place) + run-count
+  // array + 64-byte metadata image
+  return elem_buf_bytes() + (kChunkBytes / S) * 2 + 64;
 }
 
 // decoder: the compressed sub-chunk (metadata + arrays) is staged in LDS,
@@ -233,9 +237,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
     return;
   uint8_t* my = smem + wave * wave_lds_bytes<S>();
   UT* bufA = reinterpret_cast<UT*>(my);
-  UT* bufB = reinterpret_cast<UT*>(my + elem_buf_bytes());
-  uint16_t* cnts = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes());
-  uint32_t* meta = reinterpret_cast<uint32_t*>(my + 2 * elem_buf_bytes() + (kChunkBytes / S) * 2);
+  uint16_t* cnts = reinterpret_cast<uint16_t*>(my + elem_buf_bytes());
+  uint32_t* meta = reinterpret_cast<uint32_t*>(my + elem_buf_bytes() + (kChunkBytes / S) * 2);
 
   cgptr in = to_global(uniform_ptr(in_ptrs[part]));
   const size_t in_bytes64 = uniform((uint64_t)in_bytes_arr[part]);
@@ -278,12 +281,15 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
       if (lane < 16)
         meta[lane] = 0;
     }
-    UT* x = bufA;
-    UT* y = bufB;
+    // Both layers work in place: a step reads elements [base, base + 64] and
+    // then writes at or below base + 63 (RLE compacts, delta keeps the
+    // index), LDS operations of a wave execute in order, and within a step
+    // every lane's loads precede every lane's store.
+    UT* const x = bufA;
     int rr = R, dr = D;
     for (int l = 0; l < layers && use; ++l) {
       if (rr > 0) { // reference :913-953
-        const uint32_t m = wave_rle<UT>(x, n, y, cnts, lane);
+        const uint32_t m = wave_rle<UT>(x, n, x, cnts, lane);
         const uint32_t ob = wave_write_array<uint16_t>(out, cur, limit, cnts, m, bp, lane);
         if (ob == 0xFFFFFFFFu) {
           use = false;
@@ -292,7 +298,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
         cur += ru(ob, 4);
         if (lane == 0)
           meta[R - rr + 1] = ob;
-        UT* t = x; x = y; y = t;
         n = m;
         --rr;
       }
@@ -303,9 +308,11 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
         }
         if (lane == 0)
           *reinterpret_cast<UT*>(reinterpret_cast<uint8_t*>(meta) + dh_off + (D - dr) * S) = x[0];
-        for (uint32_t i = (uint32_t)lane; i + 1 < n; i += kWave)
-          y[i] = (UT)(x[i + 1] - x[i]);
-        UT* t = x; x = y; y = t;
+        for (uint32_t i = (uint32_t)lane; i + 1 < n; i += kWave) {
+          const UT hi = x[i + 1], lo = x[i];
+          lds_lane_exchange_fence();
+          x[i] = (UT)(hi - lo);
+        }
         n -= 1;
         --dr;
       }

@@ -183,3 +183,22 @@ def tpch_lineitem_text(seed: int, n_bytes: int) -> bytes:
     while len(text) < n_bytes:
         text += text
     return text[:n_bytes]
+
+
+def sparse_repeats(seed: int, n: int, every: int, length: int) -> bytes:
+    """Incompressible bytes with a copy of `length` earlier bytes planted about every `every`
+    bytes: long match-less stretches (the LZ4 encoder's pipelined walk) that end in a match at
+    an arbitrary lane of an arbitrary window (its roll-back)."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, n, dtype=np.uint8)
+    pos = 0
+    while True:
+        pos += int(rng.integers(every // 2, every * 3 // 2 + 1))
+        if pos + length >= n:
+            break
+        back = int(rng.integers(1, min(pos, 65535) + 1))
+        src = pos - back
+        for k in range(length):  # byte by byte: overlapping copies stay LZ-like
+            a[pos + k] = a[src + k]
+        pos += length
+    return a.tobytes()

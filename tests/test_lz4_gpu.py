@@ -48,6 +48,59 @@ def test_edge_chunks_bit_exact(hc, oracle, reflib, cuda, tname, dtype, es):
         assert codec.get_decompress_size(mine).cpu().tolist() == [len(c) for c in chunks]
 
 
+@pytest.mark.parametrize("tname,dtype,es", TYPES)
+def test_sparse_matches_walk_and_rollback(hc, oracle, reflib, cuda, tname, dtype, es):
+    """Long match-less stretches that end in a match: the encoder's pipelined
+    walk, its roll-back (match in the older of the two windows in flight, at
+    any lane), its exits at the last full window, and the re-arming after a
+    match.  More chunks than one workgroup holds, of different sizes, so that
+    waves draw tickets at different times."""
+    chunks = []
+    for k, (every, length) in enumerate([(200, 4), (200, 9), (700, 5), (3000, 40), (61, 4), (64, 6), (5000, 300), (129, 4)]):
+        for n in (65536, 65535 - 7 * k, 20000 + 13 * k, 257 + k):
+            chunks.append(datagen.sparse_repeats(100 + k, n, every, length))
+    chunks.append(bytes(np.random.default_rng(9).integers(0, 256, 65536, dtype=np.uint8)))  # no match at all
+    chunks = [c[: len(c) // es * es] if es > 1 else c for c in chunks]
+    src, mine, ref = _compress_both(hc, reflib, chunks, dtype, 65536)
+    got = mine.to_host_chunks()
+    refgot = ref.to_host_chunks() if ref is not None else None
+    for i, c in enumerate(chunks):
+        want = oracle.lz4_compress(c, es, 65536)
+        assert got[i] == want, f"chunk {i} {tname}: kernel != oracle"
+        if refgot is not None:
+            assert refgot[i] == want, f"chunk {i} {tname}: oracle != reference"
+    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
+    dec, actual, statuses = codec.decompress(mine, 65536)
+    assert statuses.cpu().tolist() == [0] * len(chunks)
+    assert dec.to_host_chunks() == chunks
+
+
+def test_small_tables_many_waves_per_group(hc, oracle, cuda):
+    """max_chunk below 16 KiB: smaller hash tables, up to 16 waves (= chunks
+    in flight) per workgroup, batch sizes that do not fill the last group."""
+    rng = np.random.default_rng(21)
+    for max_chunk, nchunks in ((100, 37), (1000, 50), (4096, 33), (8192, 21)):
+        chunks = []
+        for i in range(nchunks):
+            n = int(rng.integers(0, max_chunk + 1))
+            kind = i % 3
+            if kind == 0:
+                chunks.append(bytes(rng.integers(0, 256, n, dtype=np.uint8)))
+            elif kind == 1:
+                chunks.append(datagen.text_like(i, n))
+            else:
+                chunks.append(datagen.sparse_repeats(i, n, 150, 6) if n > 400 else bytes(rng.integers(0, 4, n, dtype=np.uint8)))
+        src = hc.batch.from_host_chunks(chunks, "cuda:0")
+        codec = hc.batch.Codec("LZ4", hc.LZ4Opts(0))
+        mine = codec.compress(src, max_chunk)
+        got = mine.to_host_chunks()
+        for i, c in enumerate(chunks):
+            assert got[i] == oracle.lz4_compress(c, 1, max_chunk), f"max_chunk={max_chunk} chunk {i}"
+        dec, actual, statuses = codec.decompress(mine, max(max_chunk, 8))
+        assert statuses.cpu().tolist() == [0] * len(chunks)
+        assert dec.to_host_chunks() == chunks
+
+
 def test_large_chunks_beyond_64k(hc, oracle, reflib, cuda):
     """> 65536 elements: exercises the 16-bit position wrap of the hash table.
     In typed modes the reference truncates byte offsets > 65535 (a corrupt

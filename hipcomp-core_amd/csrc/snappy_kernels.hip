@@ -183,37 +183,44 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     // ---- StoreLiterals / StoreCopy (reference :73-151).  The output buffer
     // holds 32 + n + n/6 bytes by contract, which this encoder cannot exceed
     // (DESIGN.md), so the reference's per-byte bounds checks are not needed.
-    if (lit > 0) {
-      const uint32_t lm1 = lit - 1;
-      if (lm1 < 60) {
-        if (lane == 0)
-          dst[c] = (uint8_t)(lm1 << 2);
-        c += 1;
-      } else { // lit <= 256 -> one length byte
-        if (lane == 0) {
-          dst[c] = (uint8_t)(60 << 2);
-          dst[c + 1] = (uint8_t)lm1;
-        }
-        c += 2;
-      }
-      wave_copy(dst + c, src + pos0, lit, lane);
-      c += lit;
-    }
+    // The copy element as up to three bytes (wave-uniform)
+    uint32_t copy_tag = 0, copy_bytes = 0;
     if (copy_len > 0) {
       if (copy_len < 12 && distance < 2048) {
-        if (lane == 0) {
-          dst[c] = (uint8_t)(((distance & 0x700u) >> 3) | ((copy_len - 4) << 2) | 0x01u);
-          dst[c + 1] = (uint8_t)distance;
-        }
-        c += 2;
+        copy_tag = (((distance & 0x700u) >> 3) | ((copy_len - 4) << 2) | 0x01u) | ((distance & 0xFFu) << 8);
+        copy_bytes = 2;
       } else {
-        if (lane == 0) {
-          dst[c] = (uint8_t)(((copy_len - 1) << 2) | 0x2u);
-          dst[c + 1] = (uint8_t)distance;
-          dst[c + 2] = (uint8_t)(distance >> 8);
-        }
-        c += 3;
+        copy_tag = (((copy_len - 1) << 2) | 0x2u) | (distance << 8);
+        copy_bytes = 3;
       }
+    }
+    if (lit <= 60) {
+      // Common case: literal tag (one byte), literals and copy element are at
+      // most 64 bytes -- ONE byte-per-lane store instead of three lane-0
+      // stores and a general copy.
+      const uint32_t hdr = lit > 0 ? 1u : 0u;
+      const uint32_t cb = hdr + lit; // where the copy element starts
+      const uint32_t i = (uint32_t)lane;
+      uint32_t b = (lit - 1u) << 2; // lane 0 of a literal element: its tag
+      if (i >= hdr && i < cb)
+        b = src[pos0 + i - hdr];
+      if (i >= cb)
+        b = copy_tag >> (8u * (i - cb));
+      if (i < cb + copy_bytes)
+        dst[c + i] = (uint8_t)b;
+      c += cb + copy_bytes;
+    } else {
+      const uint32_t lm1 = lit - 1; // 60 <= lm1 <= 255 -> one length byte
+      if (lane == 0) {
+        dst[c] = (uint8_t)(60 << 2);
+        dst[c + 1] = (uint8_t)lm1;
+      }
+      c += 2;
+      wave_copy(dst + c, src + pos0, lit, lane);
+      c += lit;
+      if ((uint32_t)lane < copy_bytes)
+        dst[c + lane] = (uint8_t)(copy_tag >> (8u * (uint32_t)lane));
+      c += copy_bytes;
     }
     pos = pos0 + lit + copy_len;
   }

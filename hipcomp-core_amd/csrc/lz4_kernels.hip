@@ -118,9 +118,9 @@ __device__ __forceinline__ uint32_t write_sequence(
 //                          override the first half wherever a slot also has
 //                          a window lane below 32.
 // What travels through the permute is the "insert image" of a window lane:
-// bits 0..13 slot, bit 14 "this lane stores", bits 16..31 the value.
+// bits 0..15 the value, bits 16..29 the slot, bit 31 "this lane stores".
 // ---------------------------------------------------------------------------
-constexpr uint32_t kImageStore = 1u << 14;
+constexpr uint32_t kImageStore = 1u << 31;
 
 __device__ __forceinline__ int make_insert_perm_addr4(int lane)
 {
@@ -160,14 +160,14 @@ __device__ __forceinline__ uint32_t insert_image(
   const uint64_t store = always | (unless31 & ~in31);
   uint32_t flag;
   asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(flag) : "v"(kImageStore), "s"(store));
-  const uint32_t value = lane == 31 ? slot_old : pos;
-  return hpos | flag | (value << 16);
+  const uint32_t value = lane == 31 ? slot_old : pos; // 16 bits each
+  return (hpos << 16) | flag | value;
 }
 
 __device__ __forceinline__ void store_insert_image(uint16_t* table, uint32_t image)
 {
-  if (image & kImageStore)
-    table[image & (kImageStore - 1u)] = (uint16_t)(image >> 16);
+  if ((int32_t)image < 0)
+    table[(image >> 16) & 0x3FFFu] = (uint16_t)image;
 }
 
 // n <= 31: plain store of the first n lanes.
@@ -258,14 +258,18 @@ __device__ __forceinline__ void window_candidate(
   // <= 64 KiB this never triggers, so those stay bit-identical
   // (DESIGN.md "deliberate deviations").
 #ifdef HC_ABL_NO_VERIFY
-  const bool probe = false;
+  W.probe = 0;
 #else
-  const bool probe = W.valid & (W.h_old != kNullOffset) & (back < 65535u / S);
+  // (one ballot per compare, combined as scalars: a ballot of the combined
+  // per-lane condition goes through a VGPR)
+  W.probe = wave_ballot(W.h_old != kNullOffset) & wave_ballot(back < 65535u / S)
+            & lanes_below<64>(W.nv);
 #endif
-  W.probe = wave_ballot(probe);
   W.cand = cand;
   const uint32_t own = FULL ? pos : min(pos, last_word);
-  W.cand_word = load_u32_any(in + (size_t)(probe ? cand : own) * S);
+  uint32_t at; // probe ? cand : own, straight from the scalar lane mask
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(at) : "v"(own), "v"(cand), "s"(W.probe));
+  W.cand_word = load_u32_any(in + (size_t)at * S);
   // Next words: not after a window with a match (this one most likely has
   // one too, the words would be dropped, and a load in flight into a
   // register the match path wants to reuse makes that path wait for it).

@@ -426,25 +426,37 @@ __device__ __forceinline__ uint32_t match_length(
   return limit;
 }
 
-// One step of the pipelined walk: P has had its table half and its insert, N
-// is the window behind it.  N's table half overlaps P's decision half.
-//   kWalkOn     P had no match, N took P's place (N inserted, undecided)
-//   kWalkMatch  P has the match D; N's markers are off the table again, P's
-//               full insert still has to be cut back (window_insert_first)
-//   kWalkEnd    P had no match and no full window follows N; D is N's decision
-constexpr int kWalkOn = 0, kWalkMatch = 1, kWalkEnd = 2;
+// One step of the pipelined walk.  Three windows are in flight: P and Q have
+// had their table half and their insert (on the guess that they have no
+// match), N is the window behind Q.  N's table half runs while P's
+// verification load -- issued two steps ago -- is in its last stretch; P's
+// decision is then, nearly always, one cheap test.
+//   kWalkOn     P had no match; Q, N and the next window move up
+//   kWalkMatch  P has the match D; N's markers and Q's insert are off the
+//               table again, P's full insert still has to be cut back
+//               (window_insert_first)
+//   kWalkDrain  P had no match and no full window follows N: N is inserted,
+//               Q and N are still to be decided, in this order
+constexpr int kWalkOn = 0, kWalkMatch = 1, kWalkDrain = 2;
+
+// Puts back what W's slots held before W (its markers or its insert).
+__device__ __forceinline__ void window_undo(const Window& W, uint16_t* table)
+{
+  if (W.valid)
+    table[W.hpos] = (uint16_t)W.h_old;
+  lds_lane_exchange_fence();
+}
 
 template <int S, int NVMAX>
 __device__ __forceinline__ int walk_step(
-    const Window& P, Window& N, uint32_t& words_behind, Decision& D, uint16_t* table, cgptr in,
+    const Window& P, const Window& Q, Window& N, Decision& D, uint16_t* table, cgptr in,
     uint32_t L, uint32_t last_word, uint32_t hmask, uint32_t rev_lane, int rev_addr4,
     int perm_addr4, int lane)
 {
   constexpr uint32_t LVM = (12 + S - 1) / S;
   uint32_t prN;
-  // words_behind: the words of the window behind the newest one
-  window_begin<S, NVMAX, true>(N, P.d + (uint32_t)NVMAX, words_behind, L, hmask, lane);
-  words_behind = P.next_word;
+  // every window loads the words of the window two behind it: N's are P's
+  window_begin<S, NVMAX, true>(N, Q.d + (uint32_t)NVMAX, P.next_word, L, hmask, lane);
   lds_read_u16_with_bpermute(
       table + N.hpos, rev_addr4, N.hpos | (N.valid ? 0x80000000u : 0u), N.h_old, prN);
   window_candidate<S, true>(N, in, last_word, lane, true, 2);
@@ -460,18 +472,13 @@ __device__ __forceinline__ int walk_step(
         (int)(window_winner(P, lane) * 4u), (int)P.word);
     D = window_decide<NVMAX>(P, nwP, lane);
     if (D.match) {
-      if (N.valid)
-        table[N.hpos] = (uint16_t)N.h_old;
-      lds_lane_exchange_fence();
+      window_undo(N, table); // newest first: N read its slots after Q's insert
+      window_undo(Q, table);
       return kWalkMatch;
     }
     if (last) {
-      // no full window behind N: decide N on its own
       store_insert_image(table, N.pimage);
-      const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
-          (int)(window_winner(N, lane) * 4u), (int)N.word);
-      D = window_decide<NVMAX>(N, nw, lane);
-      return kWalkEnd;
+      return kWalkDrain;
     }
   }
   store_insert_image(table, N.pimage);
@@ -590,16 +597,14 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
 
   uint32_t token_start = 0; // first element not yet written out
   while (d < L) {
-    if (cold && (int)(L - d - LVM) >= 2 * NVMAX) {
-      // ---- pipelined walk over match-less full windows (here: a full
-      // window follows this full window).  P's insert is done at once, on
-      // the guess that P has no match; the table half of the following window
-      // N then overlaps P's decision half.  If P does have a match, N is
-      // dropped and the table is put back.
-      Window A, B, P;
+    if (cold && (int)(L - d - LVM) >= 3 * NVMAX) {
+      // ---- pipelined walk over match-less full windows (here: three full
+      // windows lie ahead).  A window's insert is done at once, on the guess
+      // that it has no match; its decision follows two windows later, when
+      // its verification load has had two steps to arrive.  A match rolls the
+      // table back and drops the newer windows.
+      Window A, B, C, W; // W: the window the walk ended on
       Decision D;
-      uint32_t words_behind = load_u32_any(
-          in + (size_t)min(d + (uint32_t)(NVMAX + lane), last_word) * S);
       {
         uint32_t pr;
         window_begin<S, NVMAX, true>(A, d, next, L, hmask, lane);
@@ -608,33 +613,67 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
         window_candidate<S, true>(A, in, last_word, lane, true, 2);
         window_markers<NVMAX>(A, table, pr, rev_lane, perm_addr4, lane);
         store_insert_image(table, A.pimage);
+        const uint32_t wordsB = load_u32_any(
+            in + (size_t)min(d + (uint32_t)(NVMAX + lane), last_word) * S);
+        window_begin<S, NVMAX, true>(B, d + (uint32_t)NVMAX, wordsB, L, hmask, lane);
+        lds_read_u16_with_bpermute(
+            table + B.hpos, rev_addr4, B.hpos | (B.valid ? 0x80000000u : 0u), B.h_old, pr);
+        window_candidate<S, true>(B, in, last_word, lane, true, 2);
+        window_markers<NVMAX>(B, table, pr, rev_lane, perm_addr4, lane);
+        store_insert_image(table, B.pimage);
       }
-      // the two windows in flight swap roles from step to step (no copies)
+      // the three windows in flight rotate through the roles (no copies)
+      Window Qd, Nd; // on kWalkDrain: the two undecided windows
+      int r;
       for (;;) {
-        int r = walk_step<S, NVMAX>(A, B, words_behind, D, table, in, L, last_word, hmask,
-                                    rev_lane, rev_addr4, perm_addr4, lane);
+        r = walk_step<S, NVMAX>(A, B, C, D, table, in, L, last_word, hmask, rev_lane,
+                                rev_addr4, perm_addr4, lane);
         if (r != kWalkOn) {
-          P = r == kWalkMatch ? A : B;
+          W = A; Qd = B; Nd = C;
           break;
         }
-        r = walk_step<S, NVMAX>(B, A, words_behind, D, table, in, L, last_word, hmask,
-                                rev_lane, rev_addr4, perm_addr4, lane);
+        r = walk_step<S, NVMAX>(B, C, A, D, table, in, L, last_word, hmask, rev_lane,
+                                rev_addr4, perm_addr4, lane);
         if (r != kWalkOn) {
-          P = r == kWalkMatch ? B : A;
+          W = B; Qd = C; Nd = A;
           break;
+        }
+        r = walk_step<S, NVMAX>(C, A, B, D, table, in, L, last_word, hmask, rev_lane,
+                                rev_addr4, perm_addr4, lane);
+        if (r != kWalkOn) {
+          W = C; Qd = A; Nd = B;
+          break;
+        }
+      }
+      if (r == kWalkDrain) {
+        // the oldest window had no match; the two behind it, oldest first
+        const uint32_t nwQ = (uint32_t)__builtin_amdgcn_ds_bpermute(
+            (int)(window_winner(Qd, lane) * 4u), (int)Qd.word);
+        D = window_decide<NVMAX>(Qd, nwQ, lane);
+        if (D.match) {
+          window_undo(Nd, table);
+          W = Qd;
+        } else {
+          const uint32_t nwN = (uint32_t)__builtin_amdgcn_ds_bpermute(
+              (int)(window_winner(Nd, lane) * 4u), (int)Nd.word);
+          D = window_decide<NVMAX>(Nd, nwN, lane);
+          W = Nd;
         }
       }
       if (D.match) {
-        window_insert_first<NVMAX>(P, table, D.f, perm_addr4, lane);
-        emit_match<S>(out, c, in, token_start, P.d, P.word, D, L, lane, d);
+        window_insert_first<NVMAX>(W, table, D.f, perm_addr4, lane);
+        emit_match<S>(out, c, in, token_start, W.d, W.word, D, L, lane, d);
         next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
         token_start = d;
         cold = false;
         continue;
       }
-      d = P.d + (uint32_t)NVMAX;
-      next = words_behind;
-      // (at least one more window follows, not a full pair)
+      // (only after a drain: W is the last window, its words-two-behind load
+      // belongs to the window after the next one, so the next one's words
+      // are those its predecessor loaded)
+      d = W.d + (uint32_t)NVMAX;
+      next = Qd.next_word;
+      // (at least one more window follows, not three full ones)
     }
 
     if (d + LVM >= L) {

@@ -175,7 +175,7 @@ int oracle_cascaded_compress(
     const uint8_t* in, size_t in_bytes, int type, int s, int R, int D, int bp,
     uint8_t* out, uint8_t* mask, size_t* out_bytes)
 {
-  static uint64_t a[CHUNK_BYTES], b[CHUNK_BYTES], cnt[CHUNK_BYTES];
+  static __thread uint64_t a[CHUNK_BYTES], b[CHUNK_BYTES], cnt[CHUNK_BYTES]; /* per thread: bench_codecs.py times this from a thread pool */
   const size_t cap = oracle_cascaded_max_compressed_size(in_bytes);
   memset(out, 0, cap);
   memset(mask, 0, cap);
@@ -332,7 +332,7 @@ static long read_array(
 int oracle_cascaded_decompress(
     const uint8_t* comp, size_t comp_bytes, uint8_t* out, size_t cap, size_t* actual)
 {
-  static uint64_t a[CHUNK_BYTES], b[CHUNK_BYTES], cnt[CHUNK_BYTES];
+  static __thread uint64_t a[CHUNK_BYTES], b[CHUNK_BYTES], cnt[CHUNK_BYTES]; /* per thread: bench_codecs.py times this from a thread pool */
   static const int sizes[8] = {1, 1, 2, 2, 4, 4, 8, 8};
   *actual = 0;
   if (comp_bytes < PART_META)

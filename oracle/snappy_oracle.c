@@ -180,7 +180,7 @@ static uint32_t find_four_byte_match(
 /* do_snap :281-385.  dst must hold oracle_snappy_max_compressed_size(len). */
 int oracle_snappy_compress(const uint8_t* src, size_t len64, uint8_t* dst, size_t* out_len)
 {
-  static uint16_t hash_map[1 << HASH_BITS];
+  static __thread uint16_t hash_map[1 << HASH_BITS]; /* per thread, see cascaded_oracle.c */
   const uint32_t len = (uint32_t)len64;
   uint8_t* const base = dst;
   uint8_t* const end = dst + oracle_snappy_max_compressed_size(len);

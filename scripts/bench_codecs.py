@@ -17,6 +17,8 @@ ap.add_argument("--chunks", type=int, default=20000)
 ap.add_argument("--codec", default="both")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--no-ref", action="store_true")
+ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline line")
+ap.add_argument("--cpu-sample-chunks", type=int, default=1024)
 ap.add_argument("--extra-lib", action="append", default=[], help="name=path of another build of this library to time next to it")
 a = ap.parse_args()
 hc = importlib.import_module("hipcomp-core_amd")
@@ -80,10 +82,42 @@ def run(codec_name, opts, data):
     return results
 
 
+def cpu_baseline(codec_name, host: np.ndarray):
+    """CPU port (oracle/, scalar C) of the same codec on a bounded sample of the same data, one
+    Python thread per host core (ctypes releases the GIL).  A reported baseline, not a target:
+    SURVEY 8(d) asks for libsnappy when present -- it is not in this image -- and else for the
+    own CPU codec."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    cores = os.cpu_count() or 1
+    n = min(a.cpu_sample_chunks, host.size // CHUNK)
+    chunks = [host[i * CHUNK:(i + 1) * CHUNK].tobytes() for i in range(n)]
+    if codec_name == "Snappy":
+        enc = O.snappy_compress
+        dec = lambda z: O.snappy_decompress(z, CHUNK)
+    else:
+        enc = lambda c: O.cascaded_compress(c, 5, 2, 1, 1)[0]
+        dec = lambda z: O.cascaded_decompress(z, CHUNK)
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter(); comp = list(ex.map(enc, chunks)); t1 = time.perf_counter()
+        outs = list(ex.map(dec, comp)); t2 = time.perf_counter()
+    ok = all(o[0] == 0 and o[1] == c for o, c in zip(outs, chunks))
+    nb = n * CHUNK
+    print(json.dumps({"codec": codec_name, "lib": "cpu_baseline", "kind": "port", "cores": cores, "chunks": n,
+                      "compress_GBps": nb / (t1 - t0) / 1e9, "decompress_GBps": nb / (t2 - t1) / 1e9,
+                      "roundtrip_GBps": nb / (t2 - t0) / 1e9, "roundtrip_ok": ok,
+                      "sample": f"oracle/ C port (scalar restatement of the reference codec), {n} x 64 KiB chunks of the same data, "
+                                f"{cores} threads; libsnappy is not installed in this image"}), flush=True)
+
+
 if a.codec in ("snappy", "both"):
     text = np.frombuffer(datagen.tpch_lineitem_text(0x5EED0006, 1 << 24), dtype=np.uint8).copy()
     run("Snappy", hc.SnappyOpts(0), tile(text, a.chunks))
+    if not a.no_cpu:
+        cpu_baseline("Snappy", text)
 if a.codec in ("cascaded", "both"):
     # sorted uint32 columns, ~25% repeats, increments 1..8, one column per 64 KiB partition
     base = np.concatenate([datagen.sorted_column(0x5EED0005 + i, CHUNK // 4) for i in range(256)]).view(np.uint8)
     run("Cascaded", hc.CascadedOpts(4096, hc.hipcompType.UINT, 2, 1, 1), tile(base, a.chunks))
+    if not a.no_cpu:
+        cpu_baseline("Cascaded", base)

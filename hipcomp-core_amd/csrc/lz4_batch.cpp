@@ -111,13 +111,22 @@ hipcompStatus_t hipcompBatchedLZ4CompressAsync(
   if (batch_size > 0xFFFFFFFFull)
     return fail(fn, "batch_size must be below 2^32");
   HCAMD_DEVICE_POINTER(fn, device_temp_ptr);
+  // the chunk ticket counter: the first 4-byte aligned word of the temp
+  // buffer -- if the (contract-sized) buffer is too small to hold one, the
+  // kernel runs without it
+  uint32_t* ticket = nullptr;
+  {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(device_temp_ptr);
+    const uintptr_t aligned = (base + 3u) & ~uintptr_t(3);
+    if (aligned + sizeof(uint32_t) <= base + temp_bytes)
+      ticket = reinterpret_cast<uint32_t*>(aligned);
+  }
 
   const hipError_t e = lz4_launch_compress(
       reinterpret_cast<const uint8_t* const*>(device_uncompressed_ptrs),
       device_uncompressed_bytes,
       reinterpret_cast<uint8_t* const*>(device_compressed_ptrs),
-      device_compressed_bytes, (uint32_t)ht, batch_size, s,
-      static_cast<uint32_t*>(device_temp_ptr), stream);
+      device_compressed_bytes, (uint32_t)ht, batch_size, s, ticket, stream);
   if (e != hipSuccess)
     return fail(fn, std::string("lz4 compress launch: ") + hipGetErrorString(e));
   std::string why;

@@ -565,7 +565,10 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   // `if (lane == 0)` here sits back to back with the `if (lane == 0)` store
   // that ends the previous chunk, the compiler threads the two together and
   // the readfirstlane below then runs with lane 0 split off (seen as a hang).
-  const uint32_t chunk = uniform(atomicAdd(ticket, lane == 0 ? 1u : 0u));
+  // Without a ticket counter (temp buffer too small to hold one): one chunk
+  // per wave, numbered by position in the grid.
+  const uint32_t chunk = ticket ? uniform(atomicAdd(ticket, lane == 0 ? 1u : 0u))
+                                : (uint32_t)blockIdx.x * (uint32_t)(blockDim.x >> 6) + wave;
   if (chunk >= batch)
     break;
   cgptr __restrict__ in = to_global(in_ptrs[chunk]);
@@ -712,6 +715,8 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   }
   if (lane == 0)
     out_bytes[chunk] = c;
+  if (!ticket)
+    break;
  } // next ticket
 }
 
@@ -933,10 +938,13 @@ hipError_t lz4_launch_compress(
     size_t batch, int elem_size, uint32_t* ticket, hipStream_t stream)
 {
   const Lz4CompressShape sh = lz4_compress_shape(ht_size, batch);
-  const dim3 grid(sh.groups), block(sh.waves * kWave);
-  hipError_t e = hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
-  if (e != hipSuccess)
-    return e;
+  // ticket == nullptr: no persistent workgroups, one chunk per wave
+  const dim3 grid(ticket ? sh.groups : (unsigned)((batch + sh.waves - 1) / sh.waves)), block(sh.waves * kWave);
+  if (ticket) {
+    const hipError_t e = hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess)
+      return e;
+  }
   // more than 64 KiB of dynamic LDS has to be asked for, once per kernel
   static const hipError_t raised = [] {
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<1>),

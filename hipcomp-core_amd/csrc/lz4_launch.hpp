@@ -27,8 +27,9 @@ struct Lz4CompressShape
 Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch);
 
 // `ticket` is one zero-initialised-by-the-launcher uint32 in device memory
-// (the start of the caller's temp buffer) from which waves draw chunk
-// numbers.  batch must be > 0 and < 2^32.
+// (in the caller's temp buffer) from which the waves of the persistent
+// workgroups draw chunk numbers; nullptr = one chunk per wave, as many
+// workgroups as that takes.  batch must be > 0 and < 2^32.
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,

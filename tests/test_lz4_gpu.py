@@ -101,6 +101,29 @@ def test_small_tables_many_waves_per_group(hc, oracle, cuda):
         assert dec.to_host_chunks() == chunks
 
 
+def test_temp_buffer_of_exactly_the_contract_size(hc, oracle, cuda):
+    """The encoder keeps its chunk ticket counter in the temp buffer.  The
+    contract size can be smaller than that counter (tiny max_chunk, tiny
+    batch) and the caller's pointer need not be 4-byte aligned: nothing
+    outside [temp, temp + temp_bytes) may be written, results unchanged."""
+    import torch
+    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(0))
+    for max_chunk, chunks in ((2, [b"ab"]), (3, [b"abc", b"x"]), (1, [b"z"]), (64, [bytes(range(64))] * 3), (65536, [datagen.text_like(7, 65536)] * 7)):
+        src = hc.batch.from_host_chunks(chunks, "cuda:0")
+        need = codec.compress_temp_size(src.n, max_chunk)
+        for shift in (0, 1, 2, 3):
+            arena = torch.full((need + 64,), 0xA5, dtype=torch.uint8, device="cuda:0")
+            temp = arena[16 + shift: 16 + shift + need]
+            dst = hc.batch.alloc_batch(src.n, codec.max_output_chunk_size(max(max_chunk, 1)), "cuda:0")
+            assert codec.compress_async(src, max_chunk, temp, dst) == 0
+            torch.cuda.synchronize()
+            got = dst.to_host_chunks()
+            for i, c in enumerate(chunks):
+                assert got[i] == oracle.lz4_compress(c, 1, max_chunk), (max_chunk, shift, i)
+            a = arena.cpu().numpy()
+            assert (a[: 16 + shift] == 0xA5).all() and (a[16 + shift + need:] == 0xA5).all(), (max_chunk, shift)
+
+
 def test_large_chunks_beyond_64k(hc, oracle, reflib, cuda):
     """> 65536 elements: exercises the 16-bit position wrap of the hash table.
     In typed modes the reference truncates byte offsets > 65535 (a corrupt

@@ -210,6 +210,52 @@ def test_decoder_error_paths_match_oracle(hc, oracle, cuda):
                 assert dec.chunk_bytes(i, ac[i]) == obytes
 
 
+def _corruptions(rng, good: bytes, n: int):
+    """Valid stream with 1-3 bytes changed, a byte inserted or removed, or cut short."""
+    out = []
+    for k in range(n):
+        b = bytearray(good)
+        kind = k % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif kind == 1:
+            del b[int(rng.integers(0, len(b)))]
+        elif kind == 2:
+            b.insert(int(rng.integers(0, len(b) + 1)), int(rng.integers(0, 256)))
+        else:
+            b = b[: int(rng.integers(1, len(b)))]
+        out.append(bytes(b))
+    return out
+
+
+def test_corrupted_streams_decode_like_the_oracle(hc, oracle, cuda):
+    """Status, reported size and (on success) bytes of damaged streams: the
+    register-window fast path and the general path of the decoder must agree
+    with the oracle everywhere, not only on valid input."""
+    rng = np.random.default_rng(1234)
+    sources = [datagen.text_like(11, 3000), datagen.harness_like_int32(12, 600).tobytes(),
+               datagen.sparse_repeats(13, 4000, 90, 7), datagen.random_runs_int32(14, 700).tobytes()]
+    streams = []
+    for src in sources:
+        good = oracle.lz4_compress(src, 1, 65536)
+        streams += [good] + _corruptions(rng, good, 60)
+    for cap in (4000, 2400):
+        comp = hc.batch.from_host_chunks(streams, "cuda:0")
+        codec = hc.batch.Codec("LZ4")
+        dec, actual, statuses = codec.decompress(comp, cap)
+        st, ac = statuses.cpu().tolist(), actual.cpu().tolist()
+        sizes = codec.get_decompress_size(comp).cpu().tolist()
+        for i, s in enumerate(streams):
+            ost, obytes = oracle.lz4_decompress(s, cap)
+            assert st[i] == ost, (i, cap)
+            assert ac[i] == len(obytes), (i, cap)
+            if ost == 0:
+                assert dec.chunk_bytes(i, ac[i]) == obytes, (i, cap)
+            sst, ssize = oracle.lz4_decompressed_size(s)
+            assert sizes[i] == (ssize if sst == 0 else 0), (i, "size query")
+
+
 def test_decodes_liblz4_streams(hc, cuda):
     """Streams from the system liblz4 (a different, valid encoder) decode."""
     try:

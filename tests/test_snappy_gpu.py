@@ -119,6 +119,40 @@ def test_decoder_error_paths_match_oracle(hc, oracle, cuda):
     assert sizes == [oracle.snappy_uncompressed_size(s) for s in streams]
 
 
+def test_corrupted_streams_decode_like_the_oracle(hc, oracle, cuda):
+    """Status and reported size (and bytes on success) of damaged streams."""
+    rng = np.random.default_rng(4321)
+    sources = [datagen.text_like(21, 3000), datagen.harness_like_int32(22, 600).tobytes(),
+               datagen.tpch_lineitem_text(23, 4000)]
+    streams = []
+    for src in sources:
+        good = oracle.snappy_compress(src)
+        streams.append(good)
+        for k in range(60):
+            b = bytearray(good)
+            kind = k % 4
+            if kind == 0:
+                for _ in range(int(rng.integers(1, 4))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif kind == 1:
+                del b[int(rng.integers(0, len(b)))]
+            elif kind == 2:
+                b.insert(int(rng.integers(0, len(b) + 1)), int(rng.integers(0, 256)))
+            else:
+                b = b[: int(rng.integers(1, len(b)))]
+            streams.append(bytes(b))
+    for cap in (4000, 2500):
+        comp = hc.batch.from_host_chunks(streams, "cuda:0")
+        dec, actual, statuses = hc.batch.Codec("Snappy").decompress(comp, cap)
+        st, ac = statuses.cpu().tolist(), actual.cpu().tolist()
+        for i, s in enumerate(streams):
+            ost, obytes = oracle.snappy_decompress(s, cap)
+            assert st[i] == ost, (i, cap)
+            assert ac[i] == len(obytes), (i, cap)
+            if ost == 0:
+                assert dec.chunk_bytes(i, ac[i]) == obytes, (i, cap)
+
+
 def test_large_chunks(hc, oracle, reflib, cuda):
     """Chunks far beyond 64 KiB: the 16-bit hash-map positions wrap and copy
     distances stay <= 32768."""

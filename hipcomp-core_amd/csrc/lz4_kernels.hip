@@ -291,7 +291,12 @@ __device__ __forceinline__ void window_candidate(
 // window WITHOUT a match (all nv lanes, reference :958-962); storing that image
 // overwrites every marker but the one of lane 31's slot, whose old content the
 // image carries (insert_image).  Nothing is waited for here.
-template <int NVMAX, bool WITH_IMAGE = true>
+// FULL: all NVMAX lanes are valid and `pr` is the plain slot of the mirrored
+// lane -- except that the 64 - NVMAX lanes mirroring the invalid window lanes
+// were handed window lane 0's slot: they post into it unconditionally and
+// always lose to window lane 0 itself (the highest physical lane), so the
+// marker store needs no exec mask.
+template <int NVMAX, bool WITH_IMAGE = true, bool FULL = false>
 __device__ __forceinline__ void window_markers(
     Window& W, uint16_t* table, uint32_t pr, uint32_t rev_lane, int perm_addr4, int lane)
 {
@@ -300,7 +305,9 @@ __device__ __forceinline__ void window_markers(
     image = insert_image<NVMAX>(
         W.hpos, (W.d + (uint32_t)lane) & 0xFFFFu, W.h_old, W.nv, lane, true);
   lds_lane_exchange_fence();
-  if (pr & 0x80000000u)
+  if (FULL)
+    table[pr] = (uint16_t)rev_lane;
+  else if (pr & 0x80000000u)
     table[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
   lds_lane_exchange_fence();
   W.w_raw = table[W.hpos];
@@ -450,17 +457,16 @@ __device__ __forceinline__ void window_undo(const Window& W, uint16_t* table)
 template <int S, int NVMAX>
 __device__ __forceinline__ int walk_step(
     const Window& P, const Window& Q, Window& N, Decision& D, uint16_t* table, cgptr in,
-    uint32_t L, uint32_t last_word, uint32_t hmask, uint32_t rev_lane, int rev_addr4,
+    uint32_t L, uint32_t last_word, uint32_t hmask, uint32_t rev_lane, int rev_addr4_full,
     int perm_addr4, int lane)
 {
   constexpr uint32_t LVM = (12 + S - 1) / S;
   uint32_t prN;
   // every window loads the words of the window two behind it: N's are P's
   window_begin<S, NVMAX, true>(N, Q.d + (uint32_t)NVMAX, P.next_word, L, hmask, lane);
-  lds_read_u16_with_bpermute(
-      table + N.hpos, rev_addr4, N.hpos | (N.valid ? 0x80000000u : 0u), N.h_old, prN);
+  lds_read_u16_with_bpermute(table + N.hpos, rev_addr4_full, N.hpos, N.h_old, prN);
   window_candidate<S, true>(N, in, last_word, lane, true, 2);
-  window_markers<NVMAX>(N, table, prN, rev_lane, perm_addr4, lane);
+  window_markers<NVMAX, true, true>(N, table, prN, rev_lane, perm_addr4, lane);
   // Nearly always P has no slot shared by two lanes (so neither a duplicate
   // nor anything for the exact fallback) and no verified candidate: one test
   // for all of that (and for "N is the last full window") instead of the
@@ -559,6 +565,9 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   const int perm_addr4 = make_insert_perm_addr4(lane);
   const uint32_t rev_lane = 63u - (uint32_t)lane;
   const int rev_addr4 = (int)(rev_lane * 4u);
+  // for full windows: the lanes that mirror the invalid window lanes take
+  // window lane 0's slot instead (window_markers)
+  const int rev_addr4_full = lane < INV ? 0 : rev_addr4;
 
  for (;;) {
   // Every lane takes part in the atomic (lane 0 adds 1, the others 0): a
@@ -611,18 +620,16 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
       {
         uint32_t pr;
         window_begin<S, NVMAX, true>(A, d, next, L, hmask, lane);
-        lds_read_u16_with_bpermute(
-            table + A.hpos, rev_addr4, A.hpos | (A.valid ? 0x80000000u : 0u), A.h_old, pr);
+        lds_read_u16_with_bpermute(table + A.hpos, rev_addr4_full, A.hpos, A.h_old, pr);
         window_candidate<S, true>(A, in, last_word, lane, true, 2);
-        window_markers<NVMAX>(A, table, pr, rev_lane, perm_addr4, lane);
+        window_markers<NVMAX, true, true>(A, table, pr, rev_lane, perm_addr4, lane);
         store_insert_image(table, A.pimage);
         const uint32_t wordsB = load_u32_any(
             in + (size_t)min(d + (uint32_t)(NVMAX + lane), last_word) * S);
         window_begin<S, NVMAX, true>(B, d + (uint32_t)NVMAX, wordsB, L, hmask, lane);
-        lds_read_u16_with_bpermute(
-            table + B.hpos, rev_addr4, B.hpos | (B.valid ? 0x80000000u : 0u), B.h_old, pr);
+        lds_read_u16_with_bpermute(table + B.hpos, rev_addr4_full, B.hpos, B.h_old, pr);
         window_candidate<S, true>(B, in, last_word, lane, true, 2);
-        window_markers<NVMAX>(B, table, pr, rev_lane, perm_addr4, lane);
+        window_markers<NVMAX, true, true>(B, table, pr, rev_lane, perm_addr4, lane);
         store_insert_image(table, B.pimage);
       }
       // the three windows in flight rotate through the roles (no copies)
@@ -630,19 +637,19 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
       int r;
       for (;;) {
         r = walk_step<S, NVMAX>(A, B, C, D, table, in, L, last_word, hmask, rev_lane,
-                                rev_addr4, perm_addr4, lane);
+                                rev_addr4_full, perm_addr4, lane);
         if (r != kWalkOn) {
           W = A; Qd = B; Nd = C;
           break;
         }
         r = walk_step<S, NVMAX>(B, C, A, D, table, in, L, last_word, hmask, rev_lane,
-                                rev_addr4, perm_addr4, lane);
+                                rev_addr4_full, perm_addr4, lane);
         if (r != kWalkOn) {
           W = B; Qd = C; Nd = A;
           break;
         }
         r = walk_step<S, NVMAX>(C, A, B, D, table, in, L, last_word, hmask, rev_lane,
-                                rev_addr4, perm_addr4, lane);
+                                rev_addr4_full, perm_addr4, lane);
         if (r != kWalkOn) {
           W = C; Qd = A; Nd = B;
           break;

@@ -369,11 +369,10 @@ __device__ __forceinline__ Decision window_decide(const Window& W, uint32_t nw, 
 // False only if window_decide would find no match: every valid lane is alone
 // in its slot (then it has no duplicate and nothing is unresolved) and no
 // table candidate holds its lane's word.
-__device__ __forceinline__ bool window_needs_decision(const Window& W, int lane)
+__device__ __forceinline__ uint64_t window_suspect_lanes(const Window& W, int lane)
 {
-  return (wave_ballot(window_winner(W, lane) != (uint32_t)lane)
-          | (wave_ballot(W.cand_word == W.word) & W.probe))
-         != 0;
+  return wave_ballot(window_winner(W, lane) != (uint32_t)lane)
+         | (wave_ballot(W.cand_word == W.word) & W.probe);
 }
 
 // Table state "only the first f lanes of W were inserted", from any state in
@@ -392,6 +391,26 @@ __device__ __forceinline__ void window_insert_first(
   } else {
     insert_short_window(table, W.hpos, pos16, f, lane);
   }
+}
+
+// The same group without the wait, and the wait as a separate statement that
+// hands the two results on: whatever is written between the two runs in the
+// shadow of the LDS round trip.  `done_first` is a scalar the caller wants
+// computed BEFORE the wait (it pins that computation above it; without the
+// operand the compiler may sink it below).
+__device__ __forceinline__ void lds_read_u16_with_bpermute_issue(
+    const uint16_t* slot, int bp_addr4, uint32_t bp_data, uint32_t& slot_value, uint32_t& bp_value)
+{
+  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t*)slot;
+  asm volatile("ds_read_u16 %0, %2\n\tds_bpermute_b32 %1, %3, %4"
+               : "=&v"(slot_value), "=&v"(bp_value)
+               : "v"(a), "v"(bp_addr4), "v"(bp_data)
+               : "memory");
+}
+
+__device__ __forceinline__ void lds_wait_for(uint32_t& slot_value, uint32_t& bp_value, uint64_t done_first)
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(slot_value), "+v"(bp_value) : "s"(done_first) : "memory");
 }
 
 // First mismatching element between the strings at elements `prev` and `pos`
@@ -464,7 +483,10 @@ __device__ __forceinline__ int walk_step(
   uint32_t prN;
   // every window loads the words of the window two behind it: N's are P's
   window_begin<S, NVMAX, true>(N, Q.d + (uint32_t)NVMAX, P.next_word, L, hmask, lane);
-  lds_read_u16_with_bpermute(table + N.hpos, rev_addr4_full, N.hpos, N.h_old, prN);
+  lds_read_u16_with_bpermute_issue(table + N.hpos, rev_addr4_full, N.hpos, N.h_old, prN);
+  // in the shadow of that LDS round trip: P's test (below)
+  const uint64_t suspect = window_suspect_lanes(P, lane);
+  lds_wait_for(N.h_old, prN, suspect);
   window_candidate<S, true>(N, in, last_word, lane, true, 2);
   window_markers<NVMAX, true, true>(N, table, prN, rev_lane, perm_addr4, lane);
   // Nearly always P has no slot shared by two lanes (so neither a duplicate
@@ -473,7 +495,7 @@ __device__ __forceinline__ int walk_step(
   // full decision.  A taken branch costs a lone wave ~24 cycles, an untaken
   // one ~10 (scripts/probes/branch_cost.hip).
   const bool last = (int)(L - N.d - LVM) < 2 * NVMAX;
-  if (__builtin_expect(window_needs_decision(P, lane) | last, 0)) {
+  if (__builtin_expect((suspect != 0) | last, 0)) {
     const uint32_t nwP = (uint32_t)__builtin_amdgcn_ds_bpermute(
         (int)(window_winner(P, lane) * 4u), (int)P.word);
     D = window_decide<NVMAX>(P, nwP, lane);

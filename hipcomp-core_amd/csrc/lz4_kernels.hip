@@ -425,7 +425,12 @@ __device__ __forceinline__ uint32_t match_length(
   for (uint32_t j = 0; j < limit_bytes; j += 4 * kWave) {
     const uint32_t i = j + 4u * (uint32_t)lane;
     uint32_t diff_at = 4; // byte index of first difference inside my dword
-    if (i + 4 <= limit_bytes) {
+    if (j + 4 * kWave <= limit_bytes) {
+      // (wave-uniform, the usual case: every lane's dword lies inside the
+      // limit -- no per-lane branches)
+      const uint32_t x = load_u32_any(a + i) ^ load_u32_any(b + i);
+      diff_at = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+    } else if (i + 4 <= limit_bytes) {
       const uint32_t x = load_u32_any(a + i) ^ load_u32_any(b + i);
       if (x)
         diff_at = (uint32_t)__builtin_ctz(x) >> 3;

@@ -780,8 +780,8 @@ __device__ __forceinline__ bool read_lsic(
 }
 
 // Bytes the decoder's fast path may touch from the token on: token, up to 14
-// literals, 2 offset bytes.
-constexpr uint32_t kFastSeqBytes = 17;
+// literals, 2 offset bytes, one match length byte.
+constexpr uint32_t kFastSeqBytes = 18;
 
 template <bool WRITE_OUT>
 __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_kernel(
@@ -813,27 +813,31 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
   while (c < end) {
     uint32_t tok = 0;
     bool tok_known = false;
-    // ---- fast path: token + up to 14 literals + offset inside the stream,
-    // short non-overlapping match.  Anything else takes the general path below.
+    // ---- fast paths: token, up to 14 literals, offset and at most one match
+    // length byte inside the stream; literals + match at most 64 bytes (one
+    // byte per lane).  Anything else takes the general path below.
     if (c + kFastSeqBytes <= end) {
       sw.ensure(comp, c, end, kFastSeqBytes, lane);
       const uint32_t idx = c - sw.base;
       tok = sw.bytes_at(idx) & 0xFFu;
       tok_known = true;
-      const uint32_t litf = tok >> 4, mlf = (tok & 15u) + 4u;
-      if ((litf < 15u) & (mlf < 19u)) { // both lengths in the token itself
-        const uint32_t off = sw.bytes_at(idx + 1u + litf) & 0xFFFFu;
-        // output fits, offset inside what exists, source and destination do
-        // not overlap
-        if ((d + litf + mlf <= cap) & (off != 0u) & (off <= d + litf) & (off >= mlf)) {
+      const uint32_t litf = tok >> 4, mlc = tok & 15u;
+      if (litf < 15u) { // literal length in the token itself
+        // offset (2 bytes) and the byte behind it: a length byte if the
+        // token's match field is 15
+        const uint32_t t2 = sw.bytes_at(idx + 1u + litf);
+        const uint32_t off = t2 & 0xFFFFu;
+        // One byte per lane for literals AND match: lane i < lit carries
+        // literal i, lane lit + j match byte j.  `a` is the source as an index
+        // relative to d: >= 0 means a literal of this very sequence, i.e. a
+        // byte of the stream window (for match bytes too: no round trip
+        // through the output); < 0 means earlier output.
+        const uint32_t i = (uint32_t)lane;
+        // (1) the common one: match length in the token, output fits, offset
+        // inside what exists, source and destination do not overlap
+        const uint32_t ml1 = mlc + 4u;
+        if ((mlc < 15u) & (d + litf + ml1 <= cap) & (off != 0u) & (off <= d + litf) & (off >= ml1)) {
           if (WRITE_OUT) {
-            // One byte per lane for literals AND match: lane i < lit carries
-            // literal i, lane lit + j match byte j.  `a` is the source as an
-            // index relative to d: >= 0 means a literal of this very
-            // sequence, i.e. a byte of the stream window (for match bytes
-            // too: no round trip through the output); < 0 means earlier
-            // output.
-            const uint32_t i = (uint32_t)lane;
             const int32_t a = (int32_t)(i - (i < litf ? 0u : off));
             const uint32_t sidx = idx + 1u + (uint32_t)max(a, 0);
             const uint32_t sword = (uint32_t)__builtin_amdgcn_ds_bpermute(
@@ -845,11 +849,47 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
               const uint32_t gb = *(static_cast<cgptr>(out + d) + min(a, -1));
               byte = a >= 0 ? byte : gb;
             }
-            if (i < litf + mlf)
+            if (i < litf + ml1)
               out[d + i] = (uint8_t)byte;
           }
           c += 1u + litf + 2u;
-          d += litf + mlf;
+          d += litf + ml1;
+          continue;
+        }
+        // (2) one length byte (not 255: a second one would follow) and / or
+        // a match that overlaps itself: its source repeats with period `off`
+        const bool has_ext = mlc == 15u;
+        const uint32_t ext = (t2 >> 16) & 0xFFu;
+        const uint32_t ml2 = ml1 + (has_ext ? ext : 0u);
+        const uint32_t n2 = litf + ml2;
+        if (!(has_ext & (ext == 255u)) & (n2 <= (uint32_t)kWave) & (d + n2 <= cap) & (off != 0u)
+            & (off <= d + litf)) {
+          if (WRITE_OUT) {
+            uint32_t j = i - litf; // match byte index (lanes >= lit)
+            if (off < ml2) {
+              // j mod off for j, off < 64: quotient from a float reciprocal,
+              // then one correction step either way
+              const float r = __builtin_amdgcn_rcpf((float)off);
+              const uint32_t q = (uint32_t)((float)(int)j * r);
+              int32_t rem = (int32_t)(j - q * off);
+              rem = rem < 0 ? rem + (int32_t)off : rem;
+              rem = rem >= (int32_t)off ? rem - (int32_t)off : rem;
+              j = (uint32_t)rem;
+            }
+            const int32_t a = i < litf ? (int32_t)i : (int32_t)(litf + j - off);
+            const uint32_t sidx = idx + 1u + (uint32_t)max(a, 0);
+            const uint32_t sword = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                (int)((sidx >> 2) * 4u), (int)sw.words);
+            uint32_t byte = sword >> ((sidx & 3u) * 8u);
+            if (off > litf) {
+              const uint32_t gb = *(static_cast<cgptr>(out + d) + min(a, -1));
+              byte = a >= 0 ? byte : gb;
+            }
+            if (i < n2)
+              out[d + i] = (uint8_t)byte;
+          }
+          c += 1u + litf + 2u + (has_ext ? 1u : 0u);
+          d += n2;
           continue;
         }
       }

@@ -866,16 +866,8 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
             & (off <= d + litf)) {
           if (WRITE_OUT) {
             uint32_t j = i - litf; // match byte index (lanes >= lit)
-            if (off < ml2) {
-              // j mod off for j, off < 64: quotient from a float reciprocal,
-              // then one correction step either way
-              const float r = __builtin_amdgcn_rcpf((float)off);
-              const uint32_t q = (uint32_t)((float)(int)j * r);
-              int32_t rem = (int32_t)(j - q * off);
-              rem = rem < 0 ? rem + (int32_t)off : rem;
-              rem = rem >= (int32_t)off ? rem - (int32_t)off : rem;
-              j = (uint32_t)rem;
-            }
+            if (off < ml2)
+              j = small_mod(j & 63u, off); // (lanes below lit: unused)
             const int32_t a = i < litf ? (int32_t)i : (int32_t)(litf + j - off);
             const uint32_t sidx = idx + 1u + (uint32_t)max(a, 0);
             const uint32_t sword = (uint32_t)__builtin_amdgcn_ds_bpermute(

@@ -364,7 +364,8 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
           // wave to out[] are ordered before these loads (one wave, in-order
           // vector memory, one L1).
           if ((uint32_t)lane < blen) {
-            const uint32_t k = offset >= blen ? (uint32_t)lane : (uint32_t)lane % offset;
+            // (lane % offset; for offset >= blen, i.e. no overlap, that is lane)
+            const uint32_t k = small_mod((uint32_t)lane, offset);
             out[dst_pos + lane] = out[dst_pos - offset + k];
           }
         } else {

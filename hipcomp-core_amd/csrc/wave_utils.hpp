@@ -187,6 +187,20 @@ __device__ __forceinline__ void wave_copy(
     dst[(nvec << 4) + lane] = src[(nvec << 4) + lane];
 }
 
+// j mod m for j < 64 and any m >= 1 (m wave-uniform or not): quotient from a
+// float reciprocal (exact to within one for these ranges), then one
+// correction step either way.  About 7 instructions; the compiler's generic
+// 32-bit modulo is about 25.
+__device__ __forceinline__ uint32_t small_mod(uint32_t j, uint32_t m)
+{
+  const float r = __builtin_amdgcn_rcpf((float)m);
+  const uint32_t q = (uint32_t)((float)j * r);
+  int32_t rem = (int32_t)(j - q * m);
+  rem = rem < 0 ? rem + (int32_t)m : rem;
+  rem = rem >= (int32_t)m ? rem - (int32_t)m : rem;
+  return (uint32_t)rem;
+}
+
 // ---------------------------------------------------------------------------
 // 256 bytes of a byte stream in registers: lane t holds the dword at stream
 // index base + 4t (any alignment).  A decoder reads its tags / tokens /

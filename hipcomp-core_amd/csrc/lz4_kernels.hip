@@ -29,6 +29,8 @@
 #include "lz4_launch.hpp"
 #include "wave_utils.hpp"
 
+#include <atomic>
+
 
 namespace hcamd {
 
@@ -970,15 +972,62 @@ size_t lz4_compress_lds_bytes(uint32_t ht_size)
   return (ht_size * 2 + 15) & ~15u;
 }
 
+namespace {
+
+// Per-device facts and one-time setup, looked up by the calling thread's
+// current device (one process may drive several GPUs, one thread each, as the
+// reference's callers do).  Both steps are idempotent, so a race between two
+// first callers on one device is harmless.
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_num_cus[kMaxDevices];
+std::atomic<int> g_lds_raised[kMaxDevices]; // 0 = not yet, 1 = done, < 0 = -hipError
+
+int current_device()
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+    dev = 0;
+  return dev;
+}
+
+int num_cus_of_current_device()
+{
+  const int dev = current_device();
+  int n = g_num_cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    g_num_cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
+// more than 64 KiB of dynamic LDS has to be asked for, once per kernel and device
+hipError_t raise_dynamic_lds_limit()
+{
+  const int dev = current_device();
+  const int state = g_lds_raised[dev].load(std::memory_order_acquire);
+  if (state == 1)
+    return hipSuccess;
+  if (state < 0)
+    return (hipError_t)(-state);
+  hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (r == hipSuccess)
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (r == hipSuccess)
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  g_lds_raised[dev].store(r == hipSuccess ? 1 : -(int)r, std::memory_order_release);
+  return r;
+}
+
+} // namespace
+
 Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch)
 {
-  static const int num_cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess
-        || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    return n;
-  }();
+  const int num_cus = num_cus_of_current_device();
   constexpr uint32_t kLdsPerCu = 160u * 1024u;
   Lz4CompressShape sh;
   sh.table_stride = (uint32_t)lz4_compress_lds_bytes(ht_size);
@@ -1011,18 +1060,7 @@ hipError_t lz4_launch_compress(
     if (e != hipSuccess)
       return e;
   }
-  // more than 64 KiB of dynamic LDS has to be asked for, once per kernel
-  static const hipError_t raised = [] {
-    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (r == hipSuccess)
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (r == hipSuccess)
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return r;
-  }();
+  const hipError_t raised = raise_dynamic_lds_limit();
   if (raised != hipSuccess)
     return raised;
   switch (elem_size) {

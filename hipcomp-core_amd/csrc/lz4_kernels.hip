@@ -768,17 +768,31 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
 // --------------------------------------------------------------------------
 constexpr int kDecompWavesPerBlock = 4;
 
+// Linear small-integer code: bytes are added up to and including the first one
+// that is not 0xFF (reference readLSIC).  64 bytes per step, one per lane: a
+// 64 KiB literal run has 257 of them, and one byte per step is one memory
+// round trip per byte.  False: the stream ends inside the code.
 __device__ __forceinline__ bool read_lsic(
-    cgptr comp, uint32_t& c, uint32_t end, uint32_t& num)
+    cgptr comp, uint32_t& c, uint32_t end, uint32_t& num, int lane)
 {
-  uint32_t b = 0xff;
-  while (b == 0xff) {
+  for (;;) {
     if (c >= end)
       return false;
-    b = uniform((uint32_t)comp[c++]);
-    num += b;
+    const uint32_t at = c + (uint32_t)lane;
+    const uint32_t b = at < end ? (uint32_t)comp[at] : 0u; // past the end: acts as a terminator
+    const uint64_t stop = wave_ballot(b != 0xFFu);
+    if (stop == 0) { // 64 x 0xFF, all inside the stream
+      num += 255u * (uint32_t)kWave;
+      c += (uint32_t)kWave;
+      continue;
+    }
+    const int k = __builtin_ctzll(stop);
+    if (c + (uint32_t)k >= end)
+      return false; // only 0xFF up to the end of the stream
+    num += 255u * (uint32_t)k + read_lane(b, k);
+    c += (uint32_t)k + 1u;
+    return true;
   }
-  return true;
 }
 
 // Bytes the decoder's fast path may touch from the token on: token, up to 14
@@ -892,7 +906,7 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
       tok = uniform((uint32_t)comp[c]);
     ++c;
     uint32_t lit = tok >> 4;
-    if (lit == 15 && !read_lsic(comp, c, end, lit)) {
+    if (lit == 15 && !read_lsic(comp, c, end, lit, lane)) {
       corrupt = true;
       break;
     }
@@ -920,7 +934,7 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
       const uint32_t offset = uniform((uint32_t)comp[c] | ((uint32_t)comp[c + 1] << 8));
       c += 2;
       uint32_t ml = 4 + (tok & 0x0fu);
-      if ((tok & 0x0fu) == 15 && !read_lsic(comp, c, end, ml)) {
+      if ((tok & 0x0fu) == 15 && !read_lsic(comp, c, end, ml, lane)) {
         corrupt = true;
         break;
       }

@@ -108,8 +108,8 @@ hipcompStatus_t hipcompBatchedLZ4CompressAsync(
     return fail(fn, "Unsupported input data type");
   if (batch_size == 0)
     return hipcompSuccess;
-  if (batch_size > 0xFFFFFFFFull)
-    return fail(fn, "batch_size must be below 2^32");
+  if (batch_size > 0x7FFFFFFFull) // the ticket counter runs past batch_size by up to waves x 64
+    return fail(fn, "batch_size must be below 2^31");
   HCAMD_DEVICE_POINTER(fn, device_temp_ptr);
   // the chunk ticket counter: the first 4-byte aligned word of the temp
   // buffer -- if the (contract-sized) buffer is too small to hold one, the
@@ -126,7 +126,7 @@ hipcompStatus_t hipcompBatchedLZ4CompressAsync(
       reinterpret_cast<const uint8_t* const*>(device_uncompressed_ptrs),
       device_uncompressed_bytes,
       reinterpret_cast<uint8_t* const*>(device_compressed_ptrs),
-      device_compressed_bytes, (uint32_t)ht, batch_size, s, ticket, stream);
+      device_compressed_bytes, (uint32_t)ht, batch_size, s, ticket, max_uncompressed_chunk_bytes, stream);
   if (e != hipSuccess)
     return fail(fn, std::string("lz4 compress launch: ") + hipGetErrorString(e));
   std::string why;

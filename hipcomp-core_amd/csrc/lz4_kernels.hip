@@ -562,6 +562,29 @@ __device__ __forceinline__ void emit_match(
   d_after = token_start + lit + ml;
 }
 
+// Next chunk number for this wave: one atomic by lane 0, result wave-uniform.
+// Written as one asm statement on purpose.  In C++ an `if (lane == 0)
+// atomicAdd` at the loop head sits back to back with the `if (lane == 0)`
+// store that ends the previous chunk; the compiler threaded the two together
+// and `v_readfirstlane` then ran with lane 0 split off (an endless loop).  An
+// unconditional atomic with per-lane addends (1, 0, 0, ...) avoids that but
+// becomes a 64-step serial scan in the compiler's atomic optimizer -- a third
+// of the time of a 1 KiB chunk.
+__device__ __forceinline__ uint32_t take_ticket(uint32_t* ticket, uint32_t count)
+{
+  uint32_t t;
+  const uint32_t zero = 0, one = count;
+  asm volatile("s_mov_b64 s[20:21], exec\n\t"
+               "s_mov_b64 exec, 1\n\t"
+               "global_atomic_add %0, %1, %2, %3 sc0\n\t"
+               "s_waitcnt vmcnt(0)\n\t"
+               "s_mov_b64 exec, s[20:21]"
+               : "=&v"(t)
+               : "v"(zero), "v"(one), "s"(ticket)
+               : "s20", "s21", "memory");
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+}
+
 // Workgroup shape: the hash table (ht_size x u16, 32 KiB for 64 KiB chunks)
 // is the only LDS user and LDS is what limits residency.  The CU allocates
 // LDS in 1280-byte granules, so five separate 32 KiB workgroups do not fit
@@ -578,7 +601,8 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
     const uint32_t ht_size,
     const uint32_t table_stride,
     const uint32_t batch,
-    uint32_t* __restrict__ ticket)
+    uint32_t* __restrict__ ticket,
+    const uint32_t chunks_per_ticket)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -599,16 +623,17 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   const int rev_addr4_full = lane < INV ? 0 : rev_addr4;
 
  for (;;) {
-  // Every lane takes part in the atomic (lane 0 adds 1, the others 0): a
-  // `if (lane == 0)` here sits back to back with the `if (lane == 0)` store
-  // that ends the previous chunk, the compiler threads the two together and
-  // the readfirstlane below then runs with lane 0 split off (seen as a hang).
-  // Without a ticket counter (temp buffer too small to hold one): one chunk
-  // per wave, numbered by position in the grid.
-  const uint32_t chunk = ticket ? uniform(atomicAdd(ticket, lane == 0 ? 1u : 0u))
+  // A ticket is good for chunks_per_ticket consecutive chunks (more than one
+  // for small chunks: atomics on one address run at ~85 M/s chip-wide, which
+  // would cap 1 KiB chunks at 87 GB/s).  Without a ticket counter (temp
+  // buffer too small to hold one): one chunk per wave, numbered by position
+  // in the grid.
+  const uint32_t first = ticket ? take_ticket(ticket, chunks_per_ticket)
                                 : (uint32_t)blockIdx.x * (uint32_t)(blockDim.x >> 6) + wave;
-  if (chunk >= batch)
+  if (first >= batch)
     break;
+  const uint32_t stop = ticket ? min(first + chunks_per_ticket, batch) : first + 1u;
+  for (uint32_t chunk = first; chunk < stop; ++chunk) {
   cgptr __restrict__ in = to_global(in_ptrs[chunk]);
   const uint32_t len = (uint32_t)in_bytes[chunk];
   gptr __restrict__ out = to_global(out_ptrs[chunk]);
@@ -751,6 +776,7 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   }
   if (lane == 0)
     out_bytes[chunk] = c;
+  } // next chunk of this ticket
   if (!ticket)
     break;
  } // next ticket
@@ -1064,9 +1090,16 @@ Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch)
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, uint32_t* ticket, hipStream_t stream)
+    size_t batch, int elem_size, uint32_t* ticket, size_t max_chunk_bytes, hipStream_t stream)
 {
   const Lz4CompressShape sh = lz4_compress_shape(ht_size, batch);
+  // about 16 KiB of input per ticket, but at least 4 tickets per wave so
+  // that the last ones even out the load
+  uint32_t per_ticket = 1;
+  const size_t all_waves = (size_t)sh.groups * sh.waves;
+  while (per_ticket < 64 && (size_t)per_ticket * (max_chunk_bytes ? max_chunk_bytes : 1) < 16384
+         && (size_t)per_ticket * 2 * 4 * all_waves <= batch)
+    per_ticket *= 2;
   // ticket == nullptr: no persistent workgroups, one chunk per wave
   const dim3 grid(ticket ? sh.groups : (unsigned)((batch + sh.waves - 1) / sh.waves)), block(sh.waves * kWave);
   if (ticket) {
@@ -1080,15 +1113,15 @@ hipError_t lz4_launch_compress(
   switch (elem_size) {
   case 1:
     lz4_compress_kernel<1><<<grid, block, sh.lds_bytes, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket);
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket, per_ticket);
     break;
   case 2:
     lz4_compress_kernel<2><<<grid, block, sh.lds_bytes, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket);
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket, per_ticket);
     break;
   default:
     lz4_compress_kernel<4><<<grid, block, sh.lds_bytes, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket);
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket, per_ticket);
     break;
   }
   return hipSuccess;

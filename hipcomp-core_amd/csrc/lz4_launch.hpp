@@ -29,11 +29,11 @@ Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch);
 // `ticket` is one zero-initialised-by-the-launcher uint32 in device memory
 // (in the caller's temp buffer) from which the waves of the persistent
 // workgroups draw chunk numbers; nullptr = one chunk per wave, as many
-// workgroups as that takes.  batch must be > 0 and < 2^32.
+// workgroups as that takes.  batch must be > 0 and < 2^31.
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, uint32_t* ticket, hipStream_t stream);
+    size_t batch, int elem_size, uint32_t* ticket, size_t max_chunk_bytes, hipStream_t stream);
 
 // write_out == false: parse-only pass that reports sizes.
 void lz4_launch_decompress(

@@ -50,7 +50,7 @@ hipcompStatus_t hipcompBatchedLZ4CompressGetMaxOutputChunkSize(
  * table exactly as the reference does (LZ4CompressionKernels.hip:171), so it
  * takes part in the bit-exact result.  device_temp_ptr: device memory of at
  * least hipcompBatchedLZ4CompressGetTempSize bytes (the first 4 are written).
- * batch_size < 2^32.  (reference LZ4Batch.cpp:189-224) */
+ * batch_size < 2^31.  (reference LZ4Batch.cpp:189-224) */
 hipcompStatus_t hipcompBatchedLZ4CompressAsync(
     const void* const* device_uncompressed_ptrs,
     const size_t* device_uncompressed_bytes,

@@ -4,71 +4,205 @@
 Workload (BASELINE.json configs[1]): 100 000 chunks x 64 KiB of synthetic int32
 data per GPU, through hipcompBatchedLZ4CompressAsync +
 hipcompBatchedLZ4DecompressAsync of hipcomp-core_amd/lib/libhipcomp.so.  One
-"step" = one compress pass + one decompress pass over the whole chunk list,
+"step" = one compress pass + one decompress pass over the rank's chunks,
 inputs resident in HBM.  value = uncompressed GB (1e9) through the round trip
-per second, summed over ranks (chunks are sharded, no collective: "weak").
+per second, summed over ranks.
+
+Multi-GPU (BASELINE.json configs[4]): chunks are independent, so
+rank r owns a contiguous slice of ONE seeded chunk list and no collective sits
+on the data path (no RCCL: the start/stop barrier and the two scalar
+reductions run over gloo).  Two modes, both in the JSON line when N > 1 or
+--config5 is given:
+  weak   (the headline `value`): --chunks per GPU, the list has N x chunks;
+  strong (`config5_strong`):     --total-chunks (default 163 840 = 10 GiB) in
+                                 all, rank r gets [r*ceil(B/N), (r+1)*ceil(B/N)).
 
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+`--gpus N` with N > 1 needs no launcher: when WORLD_SIZE is not set the process
+starts N child ranks itself, before anything touches the GPU.  Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it
+is one of the ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
-`roofline` (dominant kernel = the compress kernel, HBM-bound model) and
-`cpu_baseline` (system liblz4 on the host cores, bounded sample).
+`roofline` (dominant kernel = the LZ4 compress kernel, HBM-bound model),
+`cpu_baseline` (system liblz4 on the host cores, bounded sample) and, at N = 1,
+`extra_keys`: every other BASELINE config (LZ4 distributions x data types at
+the full 100 000 chunks, Snappy on TPC-H-like text, Cascaded on sorted
+columns), each with its own HBM fraction, ratio and CPU baseline.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CHUNK = 65536
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+GEN_BLOCK = 4096       # chunks per generator block: block b of the list is seeded with seed + b
+CONFIG5_TOTAL = 163840  # 10 GiB of 64 KiB chunks (BASELINE.json configs[4])
 
 
-def gen_data(dist: str, n_chunks: int, device, seed: int) -> torch.Tensor:
-    """n_chunks x 64 KiB of int32 values, generated on the device (seeded)."""
+# ---- chunk-list arithmetic (pure Python: covered by the CPU tests) -----------
+
+def shard_slice(total_chunks: int, world: int, rank: int):
+    """Contiguous slice [lo, hi) of a list of `total_chunks` for `rank`:
+    ceil(B/G) chunks per rank, the last ranks may get fewer."""
+    per = (total_chunks + world - 1) // world
+    lo = min(rank * per, total_chunks)
+    return lo, min(lo + per, total_chunks)
+
+
+def gen_blocks(lo: int, hi: int):
+    """Generator blocks that cover chunks [lo, hi): (block, first, last) with
+    first/last relative to the block."""
+    out = []
+    b = lo // GEN_BLOCK
+    while b * GEN_BLOCK < hi:
+        first = max(lo, b * GEN_BLOCK) - b * GEN_BLOCK
+        last = min(hi, (b + 1) * GEN_BLOCK) - b * GEN_BLOCK
+        out.append((b, first, last))
+        b += 1
+    return out
+
+
+def self_spawn(argv, n: int) -> int:
+    """Start n child ranks of this script (before this process has touched the
+    GPU) and wait for them; rank 0 prints the JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def aggregate_throughput(local_wall_s: float, local_bytes: int, steps: int, dist_mod=None, device=None):
+    """Whole-job GB/s: all ranks' bytes over the slowest rank's time."""
+    import torch
+    wall, total = local_wall_s, float(local_bytes)
+    if dist_mod is not None and dist_mod.is_initialized() and dist_mod.get_world_size() > 1:
+        if dist_mod.get_backend() != "nccl":
+            device = "cpu"
+        t = torch.tensor([local_wall_s], dtype=torch.float64, device=device)
+        b = torch.tensor([float(local_bytes)], dtype=torch.float64, device=device)
+        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+        dist_mod.all_reduce(b, op=dist_mod.ReduceOp.SUM)
+        wall, total = float(t.item()), float(b.item())
+    return total / (wall / steps) / 1e9, wall
+
+
+# ---- synthetic inputs (SURVEY.md 8d), generated on the device ----------------
+
+def _gen_block(dist: str, block: int, device, seed: int):
+    """GEN_BLOCK chunks x 64 KiB of int32 values: block `block` of the list `dist`/`seed`."""
+    import torch
     g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    n_ints = n_chunks * (CHUNK // 4)
-    out = torch.empty(n_ints, dtype=torch.int32, device=device)
-    piece = 1 << 26
-    for off in range(0, n_ints, piece):
-        m = min(piece, n_ints - off)
-        if dist == "uniform":      # incompressible (SURVEY 8d 2a)
-            out[off:off + m] = torch.randint(-(1 << 31), (1 << 31) - 1, (m,), dtype=torch.int64, device=device, generator=g).to(torch.int32)
-        elif dist == "harness":    # 300 + (x & 3)  (SURVEY 8d 2b)
-            out[off:off + m] = torch.randint(300, 304, (m,), dtype=torch.int32, device=device, generator=g)
-        elif dist == "runs":       # value = run index, run length U[1,16] (SURVEY 8d 2c)
-            lens = torch.randint(1, 17, (m // 8 + 16,), dtype=torch.int64, device=device, generator=g)
-            vals = torch.repeat_interleave(torch.arange(lens.numel(), dtype=torch.int32, device=device), lens)
-            while vals.numel() < m:
-                vals = torch.cat([vals, vals + vals[-1] + 1])
-            out[off:off + m] = vals[:m]
-        else:
-            raise ValueError(dist)
+    g.manual_seed(seed + block)
+    m = GEN_BLOCK * (CHUNK // 4)
+    if dist == "uniform":      # incompressible (8d 2a)
+        return torch.randint(-(1 << 31), (1 << 31) - 1, (m,), dtype=torch.int64, device=device, generator=g).to(torch.int32)
+    if dist == "harness":      # 300 + (x & 3)  (8d 2b)
+        return torch.randint(300, 304, (m,), dtype=torch.int32, device=device, generator=g)
+    if dist == "runs":         # value = run index, run length U[1,16] (8d 2c)
+        lens = torch.randint(1, 17, (m // 8 + 16,), dtype=torch.int64, device=device, generator=g)
+        vals = torch.repeat_interleave(torch.arange(lens.numel(), dtype=torch.int32, device=device), lens)
+        while vals.numel() < m:
+            vals = torch.cat([vals, vals + vals[-1] + 1])
+        return vals[:m].contiguous()
+    raise ValueError(dist)
+
+
+def gen_data(dist: str, lo: int, hi: int, device, seed: int):
+    """Chunks [lo, hi) of the seeded list, as one uint8 device buffer."""
+    import torch
+    out = torch.empty((hi - lo) * (CHUNK // 4), dtype=torch.int32, device=device)
+    at = 0
+    per = CHUNK // 4
+    for b, first, last in gen_blocks(lo, hi):
+        blk = _gen_block(dist, b, device, seed)
+        n = (last - first) * per
+        out[at:at + n] = blk[first * per:last * per]
+        at += n
+        del blk
     return out.view(torch.uint8)
 
 
-class Lz4Job:
+def gen_text(n_bytes: int, seed: int = 0x5EED0006):
+    """TPC-H lineitem-like text (8d config 4) from benchdata/tpch_text.c, host -> device."""
+    import numpy as np
+    import torch
+    path = os.path.join(ROOT, "benchdata", "libbenchdata.so")
+    B = ctypes.CDLL(path)
+    B.benchdata_tpch_lineitem_text.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int]
+    host = np.empty(n_bytes, dtype=np.uint8)
+    B.benchdata_tpch_lineitem_text(host.ctypes.data, n_bytes, seed, _cores())
+    return host
+
+
+def _splitmix(x):
+    """splitmix64 finaliser on int64 tensors (two's complement wrap-around)."""
+    x = x + (-7046029254386353131)                        # 0x9E3779B97F4A7C15
+    x = (x ^ ((x >> 30) & ((1 << 34) - 1))) * (-4658895280553007687)  # 0xBF58476D1CE4E5B9
+    x = (x ^ ((x >> 27) & ((1 << 37) - 1))) * (-7723592293110705685)  # 0x94D049BB133111EB
+    return x ^ ((x >> 31) & ((1 << 33) - 1))
+
+
+def gen_sorted_columns(n_parts: int, device, seed: int = 0x5EED0005):
+    """Config 3: one sorted uint32 column per 64 KiB partition; v[0] ~ U[0, 2^20),
+    v[i] = v[i-1] + (g == 0 ? 0 : U[1, 8]), g ~ U[0, 4) (about 25 % repeats);
+    partition i draws from the counter-based stream of seed + i."""
+    import torch
+    per = CHUNK // 4
+    out = torch.empty(n_parts * per, dtype=torch.int32, device=device)
+    step = 8192
+    j = torch.arange(per, dtype=torch.int64, device=device)
+    for p0 in range(0, n_parts, step):
+        p1 = min(p0 + step, n_parts)
+        s = (torch.arange(p0, p1, dtype=torch.int64, device=device) + seed)[:, None]
+        r = _splitmix((s << 20) + j[None, :])
+        g = r & 3
+        inc = torch.where(g == 0, torch.zeros_like(r), ((r >> 8) & 7) + 1)
+        inc[:, 0] = (r[:, 0] >> 16) & ((1 << 20) - 1)
+        v = torch.cumsum(inc, dim=1)
+        # every 1024-element sub-chunk holds at least two distinct values, so
+        # no layer sees an empty array (SURVEY.md App. C.5)
+        sub = v.view(p1 - p0, per // 1024, 1024)
+        assert bool((sub[:, :, 0] != sub[:, :, -1]).all().item())
+        out[p0 * per:p1 * per] = v.to(torch.int32).view(-1)
+        del r, g, inc, v, sub
+    return out.view(torch.uint8)
+
+
+# ---- one codec over one rank's chunks ----------------------------------------
+
+class CodecJob:
     """Buffers of one rank, allocated once like a caller of the C API would."""
 
-    def __init__(self, hc, lib, data: torch.Tensor, dtype: int):
-        self.hc = hc
-        self.codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=lib)
+    def __init__(self, hc, lib, name, opts, data):
+        import torch
+        self.codec = hc.batch.Codec(name, opts, lib=lib)
         self.src = hc.batch.from_device_buffer(data, CHUNK)
         n = self.src.n
         dev = data.device
         self.n = n
+        self.total = int(data.numel())
         self.comp = hc.batch.alloc_batch(n, self.codec.max_output_chunk_size(CHUNK), dev)
         self.temp = torch.empty(max(self.codec.compress_temp_size(n, CHUNK), 8), dtype=torch.uint8, device=dev)
         self.dtemp = torch.empty(max(self.codec.decompress_temp_size(n, CHUNK), 8), dtype=torch.uint8, device=dev)
@@ -86,15 +220,22 @@ class Lz4Job:
         assert st == 0, st
 
     def verify(self):
+        import torch
         assert int(self.statuses.abs().sum().item()) == 0, "decompress reported errors"
         assert bool((self.actual == self.src.sizes).all().item())
-        a = self.out.data[: self.n * CHUNK].view(torch.int64)
-        b = self.src.data[: self.n * CHUNK].view(torch.int64)
+        k = self.total // 8 * 8
+        a = self.out.data[:k].view(torch.int64)
+        b = self.src.data[:k].view(torch.int64)
         assert bool(torch.equal(a, b)), "round trip mismatch"
+        assert bool(torch.equal(self.out.data[k:self.total], self.src.data[k:self.total]))
+
+    def compressed_bytes(self) -> int:
+        return int(self.comp.sizes.sum().item())
 
 
-def time_phases(job: Lz4Job, steps: int):
-    """Per-step HIP-event times (ms) of the two kernels, on the launch stream."""
+def time_phases(job: CodecJob, steps: int):
+    """Per-step HIP-event times (ms) of the two launches, on the launch stream."""
+    import torch
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
     for e in evs:
         e[0].record()
@@ -108,16 +249,20 @@ def time_phases(job: Lz4Job, steps: int):
     return tc, td
 
 
-def cpu_liblz4_baseline(sample: np.ndarray, reps: int = 3):
+def _cores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_liblz4_baseline(sample, reps: int = 3):
     """System liblz4 round trip on the host cores (BASELINE.json configs[0]):
     oracle/cpu_baseline.c -- pthreads, static contiguous partition, best of
     `reps`.  Falls back to the scalar C restatement when liblz4 is absent."""
     from oracle import oracle as O
     L = O.lib()
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = _cores()
     n = sample.size // CHUNK
     tc, td, ct = ctypes.c_double(), ctypes.c_double(), ctypes.c_size_t()
     L.cpu_liblz4_roundtrip.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
@@ -144,54 +289,70 @@ def cpu_liblz4_baseline(sample: np.ndarray, reps: int = 3):
             "sample": f"oracle/lz4_oracle.c compress only, {kk} chunks (liblz4 unavailable, rc={rc})"}
 
 
-# ---- multi-GPU plumbing (chunks shard with no data-path collective) ----------
+def cpu_codec_baseline(codec: str, sample, reps: int = 2):
+    """Snappy / Cascaded round trip on the host cores (oracle/cpu_baseline.c:
+    cpu_codec_roundtrip): libsnappy when the box has it, else a plain scalar
+    Snappy encoder + the restatement's decoder; Cascaded = the C restatement."""
+    from oracle import oracle as O
+    L = O.lib()
+    cores = _cores()
+    n = sample.size // CHUNK
+    tc, td, ct, used = ctypes.c_double(), ctypes.c_double(), ctypes.c_size_t(), ctypes.c_int()
+    L.cpu_codec_roundtrip.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.cpu_codec_roundtrip(1 if codec == "Snappy" else 2, sample.ctypes.data, n, CHUNK, cores, reps,
+                               ctypes.byref(tc), ctypes.byref(td), ctypes.byref(ct), ctypes.byref(used))
+    total = n * CHUNK
+    what = ("system libsnappy (snappy_compress / snappy_uncompress)" if used.value else
+            ("libsnappy unavailable: scalar libsnappy-style encoder + oracle/snappy_oracle.c decoder"
+             if codec == "Snappy" else "oracle/cascaded_oracle.c (no third-party CPU equivalent)"))
+    return {"value": total / (tc.value + td.value) / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+            "roundtrip_ok": rc == 0,
+            "sample": f"{what}, {n} x 64KiB chunks of the same data, {cores} pthreads, best of {reps}; "
+                      f"compress {total / tc.value / 1e9:.2f} GB/s, decompress {total / td.value / 1e9:.2f} GB/s, "
+                      f"ratio {total / max(ct.value, 1):.3f}"}
 
-def shard_seed(base_seed: int, rank: int) -> int:
-    """Every rank owns its own slice of the chunk list: same size, own seed."""
-    return base_seed + rank
 
-
-def aggregate_throughput(local_wall_s: float, local_bytes: int, steps: int, dist_mod=None, device=None):
-    """Whole-job GB/s: all ranks' bytes over the slowest rank's time."""
-    wall, total = local_wall_s, float(local_bytes)
-    if dist_mod is not None and dist_mod.is_initialized() and dist_mod.get_world_size() > 1:
-        if dist_mod.get_backend() != "nccl":
-            device = "cpu"
-        t = torch.tensor([local_wall_s], dtype=torch.float64, device=device)
-        b = torch.tensor([float(local_bytes)], dtype=torch.float64, device=device)
-        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
-        dist_mod.all_reduce(b, op=dist_mod.ReduceOp.SUM)
-        wall, total = float(t.item()), float(b.item())
-    return total / (wall / steps) / 1e9, wall
-
-
-def measure_variant(hc, lib, dev, dist_name: str, dtype_name: str, chunks: int, seed: int):
-    """Compress / decompress ms of one (distribution, data_type) row."""
-    data = gen_data(dist_name, chunks, dev, seed)
-    dtype = hc.hipcompType.CHAR if dtype_name == "char" else hc.hipcompType.INT
-    job = Lz4Job(hc, lib, data, dtype)
+def measure_row(hc, lib, codec: str, opts, data, label: dict, reps: int = 2):
+    """One extra row: compress / decompress of `data` through `codec`."""
+    import torch
+    job = CodecJob(hc, lib, codec, opts, data)
     job.compress(); job.decompress(); torch.cuda.synchronize()
     job.verify()
-    tc, td = time_phases(job, 2)
-    nb, cb = job.n * CHUNK, int(job.comp.sizes.sum().item())
-    return {"distribution": dist_name, "data_type": dtype_name.upper(), "chunks": chunks, "ratio": nb / max(cb, 1),
-            "compress_GBps": nb / (min(tc) * 1e-3) / 1e9, "decompress_GBps": nb / (min(td) * 1e-3) / 1e9,
-            "roundtrip_GBps": nb / ((min(tc) + min(td)) * 1e-3) / 1e9,
-            "hbm_frac_compress": (nb + cb) / (min(tc) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    tc, td = time_phases(job, reps)
+    nb, cb = job.total, job.compressed_bytes()
+    row = dict(label)
+    row.update({"chunks": job.n, "ratio": nb / max(cb, 1),
+                "compress_GBps": nb / (min(tc) * 1e-3) / 1e9, "decompress_GBps": nb / (min(td) * 1e-3) / 1e9,
+                "roundtrip_GBps": nb / ((min(tc) + min(td)) * 1e-3) / 1e9,
+                "hbm_frac_compress": (nb + cb) / (min(tc) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "hbm_frac_decompress": (nb + cb) / (min(td) * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    del job
+    torch.cuda.empty_cache()
+    return row
 
 
-def pmc_traffic(args):
-    """HBM bytes per compress launch from the committed rocprofv3 PMC passes
+def kernel_source_id() -> str:
+    """Identifies the LZ4 kernel build a PMC pass belongs to."""
+    with open(os.path.join(ROOT, "hipcomp-core_amd", "csrc", "lz4_kernels.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_traffic(dist: str, dtype: str, chunks: int):
+    """HBM-side bytes per compress launch from the committed rocprofv3 PMC passes
     (profiles/lz4_hbm_traffic.json: FETCH_SIZE doubled as the gfx950 note in
-    MI355X_MICROARCH.md prescribes, + WRITE_SIZE), or None when no pass exists
-    for this workload."""
+    MI355X_MICROARCH.md prescribes, + WRITE_SIZE).  None when there is no pass
+    for this workload OR the pass was taken on another build of the kernel
+    (the entry records the sha256 of lz4_kernels.hip it was measured on)."""
     path = os.path.join(ROOT, "profiles", "lz4_hbm_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         table = json.load(f)
-    key = f"{args.dist}/{args.dtype}/{args.chunks}"
-    return table.get(key, {}).get("traffic_bytes_per_launch")
+    ent = table.get(f"{dist}/{dtype}/{chunks}")
+    if not ent or ent.get("kernel_source_sha16") != kernel_source_id():
+        return None
+    return ent.get("traffic_bytes_per_launch")
 
 
 def main():
@@ -199,28 +360,63 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chunks", type=int, default=100000, help="chunks per GPU")
+    ap.add_argument("--chunks", type=int, default=100000, help="chunks per GPU (weak scaling, the headline)")
+    ap.add_argument("--total-chunks", type=int, default=CONFIG5_TOTAL,
+                    help="chunks in all for the strong-scaling row (BASELINE config 5: 10 GiB)")
+    ap.add_argument("--config5", dest="config5", action="store_true", default=None,
+                    help="also run the strong-scaling row at N = 1 (default: only when N > 1)")
+    ap.add_argument("--no-config5", dest="config5", action="store_false")
     ap.add_argument("--dist", default="uniform", choices=["uniform", "harness", "runs"])
     ap.add_argument("--dtype", default="char", choices=["char", "int"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--ref", action="store_true", help="also time the reference build (oracle/_ref) on the same buffers")
     ap.add_argument("--cpu-sample-chunks", type=int, default=16384)
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / reductions "
-                    "(nccl = RCCL; gloo only for rehearsing the N>1 path on a one-GPU box)")
+    ap.add_argument("--backend", default="gloo", help="torch.distributed backend for the barrier and the two scalar "
+                    "reductions; the data path has no collective, so the default is gloo (no RCCL)")
     ap.add_argument("--no-variants", dest="variants", action="store_false",
-                    help="skip the extra (distribution, data_type) rows")
+                    help="skip the extra rows (other distributions / data types / codecs)")
+    ap.add_argument("--variant-chunks", type=int, default=100000)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="process plumbing only (spawn, rendezvous, barrier, slice arithmetic, reductions) with no "
+                         "GPU and no codec call; prints a line whose value is null -- for the CPU tests")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one.  Nothing has touched the GPU in this process.
+        sys.exit(self_spawn(sys.argv[1:], args.gpus))
+
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if args.dry_run:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        lo, hi = shard_slice(args.chunks * world, world, rank)
+        lo5, hi5 = shard_slice(args.total_chunks, world, rank)
+        v, w = aggregate_throughput(1.0 + rank, (hi - lo) * CHUNK, args.steps, dist if world > 1 else None, "cpu")
+        v5, _ = aggregate_throughput(1.0, (hi5 - lo5) * CHUNK, args.steps, dist if world > 1 else None, "cpu")
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "value": None, "n_gpus": world, "weak_bytes_per_step_GB": v * w / args.steps,
+                              "strong_bytes_per_step_GB": v5 * 1.0 / args.steps, "slowest_rank_wall_s": w}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     local = local % max(torch.cuda.device_count(), 1)  # (rehearsal: several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist_on = world > 1
+    dist = None
     if dist_on:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -229,9 +425,7 @@ def main():
     hc = importlib.import_module("hipcomp-core_amd")
     lib = hc.default_library()
     dtype = hc.hipcompType.CHAR if args.dtype == "char" else hc.hipcompType.INT
-
-    data = gen_data(args.dist, args.chunks, dev, seed=shard_seed(0x5EED0002, rank))
-    job = Lz4Job(hc, lib, data, dtype)
+    opts = hc.LZ4Opts(dtype)
 
     def barrier():
         torch.cuda.synchronize()
@@ -239,22 +433,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        job.compress()
-        job.decompress()
-    torch.cuda.synchronize()
-    job.verify()
+    def run_job(lo: int, hi: int, seed: int):
+        """Warm up, then time exactly args.steps steps of the rank's slice."""
+        data = gen_data(args.dist, lo, hi, dev, seed)
+        job = CodecJob(hc, lib, "LZ4", opts, data)
+        for _ in range(max(args.warmup, 1)):
+            job.compress()
+            job.decompress()
+        torch.cuda.synchronize()
+        job.verify()
+        barrier()
+        t0 = time.perf_counter()
+        tc, td = time_phases(job, args.steps)
+        barrier()
+        wall_local = time.perf_counter() - t0
+        value, wall = aggregate_throughput(wall_local, job.total, args.steps, dist, dev)
+        return data, job, tc, td, value, wall
 
-    barrier()
-    t0 = time.perf_counter()
-    tc, td = time_phases(job, args.steps)
-    barrier()
-    wall_local = time.perf_counter() - t0
-    n_bytes = job.n * CHUNK
-    c_bytes = int(job.comp.sizes.sum().item())
-    value, wall = aggregate_throughput(wall_local, n_bytes, args.steps, dist if dist_on else None, dev)
+    # ---- headline: weak scaling, rank r owns chunks [r*chunks, (r+1)*chunks) of one list
+    lo, hi = shard_slice(args.chunks * world, world, rank)
+    data, job, tc, td, value, wall = run_job(lo, hi, 0x5EED0002)
+    n_bytes, c_bytes = job.total, job.compressed_bytes()
     ms_step = wall / args.steps * 1e3
-
+    res = None
     if rank == 0:
         tc_avg, td_avg = sum(tc) / len(tc), sum(td) / len(td)
         algo = n_bytes + c_bytes  # per launch: N read + C written (SURVEY 8d)
@@ -267,7 +468,8 @@ def main():
                 "workload": f"hipcompBatchedLZ4 compress+decompress, {args.chunks}x64KiB int32 chunks per GPU, "
                             f"{args.dist} data, data_type={'CHAR' if args.dtype == 'char' else 'INT'}",
                 "chunks_per_gpu": args.chunks, "chunk_bytes": CHUNK, "distribution": args.dist,
-                "parallelism": f"{world} independent chunk shards, no collective",
+                "parallelism": f"{world} contiguous slices of one seeded chunk list, one process per GPU, "
+                               f"no data-path collective (barrier/reductions over {args.backend if dist_on else 'nothing'})",
             },
             "ratio": n_bytes / max(c_bytes, 1),
             "compress_GBps": n_bytes / (tc_avg * 1e-3) / 1e9,
@@ -276,15 +478,17 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "lz4_compress_kernel",
                 "achieved": algo / (tc_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": algo / (tc_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
+                "frac": algo / (tc_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(args.dist, args.dtype, args.chunks),
                 "algorithmic_bytes_per_launch": algo,
                 "decompress_achieved": algo / (td_avg * 1e-3) / 1e9,
+                "decompress_frac": algo / (td_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
         }
         if args.ref:
             from oracle import oracle as O
             if os.path.exists(O.REF_LIB_PATH):
-                rjob = Lz4Job(hc, hc.HipcompLibrary(O.REF_LIB_PATH), data, dtype)
+                rjob = CodecJob(hc, hc.HipcompLibrary(O.REF_LIB_PATH), "LZ4", opts, data)
                 rjob.compress(); rjob.decompress(); torch.cuda.synchronize()
                 rtc, rtd = time_phases(rjob, 2)
                 same = bool(torch.equal(rjob.comp.sizes, job.comp.sizes))
@@ -295,14 +499,59 @@ def main():
                     "compressed_sizes_identical": same,
                 }
                 del rjob
-        if args.variants and world == 1:
-            res["variants"] = [measure_variant(hc, lib, dev, dn, tn, min(args.chunks, 20000), 0x5EED0003 + i)
-                               for i, (dn, tn) in enumerate((("uniform", "int"), ("harness", "char"), ("runs", "char")))]
         if not args.no_cpu and world == 1:  # reported at N=1 only
             k = min(args.cpu_sample_chunks, job.n)
             res["cpu_baseline"] = cpu_liblz4_baseline(data[: k * CHUNK].cpu().numpy())
-        print(json.dumps(res))
+    del job, data
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE config 5: ONE list of --total-chunks, strong scaling
+    want5 = args.config5 if args.config5 is not None else world > 1
+    if want5:
+        lo, hi = shard_slice(args.total_chunks, world, rank)
+        data, job, tc5, td5, value5, wall5 = run_job(lo, hi, 0x5EED0002)
+        if rank == 0:
+            res["config5_strong"] = {
+                "scaling": "strong", "total_chunks": args.total_chunks, "total_bytes": args.total_chunks * CHUNK,
+                "chunks_rank0": hi - lo, "value": value5, "unit": "GB/s", "ms_per_step": wall5 / args.steps * 1e3,
+                "rank0_compress_ms": sum(tc5) / len(tc5), "rank0_decompress_ms": sum(td5) / len(td5),
+            }
+        del job, data
+        torch.cuda.empty_cache()
+
+    # ---- every other BASELINE config, N = 1 only
+    if rank == 0 and args.variants and world == 1:
+        rows = []
+        vc = args.variant_chunks
+        for i, (dn, tn) in enumerate((("uniform", "int"), ("harness", "char"), ("harness", "int"),
+                                      ("runs", "char"), ("runs", "int"))):
+            d = gen_data(dn, 0, vc, dev, {"uniform": 0x5EED0002, "harness": 0x5EED0003, "runs": 0x5EED0004}[dn])
+            t = hc.hipcompType.CHAR if tn == "char" else hc.hipcompType.INT
+            rows.append(measure_row(hc, lib, "LZ4", hc.LZ4Opts(t), d,
+                                    {"codec": "LZ4", "distribution": dn, "data_type": tn.upper()}))
+            del d
+        text_host = gen_text(1 << 30)
+        text = torch.from_numpy(text_host).to(dev)
+        rows.append(measure_row(hc, lib, "LZ4", hc.LZ4Opts(hc.hipcompType.CHAR), text,
+                                {"codec": "LZ4", "distribution": "tpch_lineitem_text", "data_type": "CHAR"}))
+        srow = measure_row(hc, lib, "Snappy", hc.SnappyOpts(0), text,
+                           {"codec": "Snappy", "config": "BASELINE configs[3]: TPC-H lineitem-like text, 1 GiB, 64 KiB chunks"})
+        if not args.no_cpu:
+            srow["cpu_baseline"] = cpu_codec_baseline("Snappy", text_host[: 2048 * CHUNK])
+        rows.append(srow)
+        del text, text_host
+        cols = gen_sorted_columns(vc, dev)
+        crow = measure_row(hc, lib, "Cascaded", hc.CascadedOpts(4096, hc.hipcompType.UINT, 2, 1, 1), cols,
+                           {"codec": "Cascaded", "config": "BASELINE configs[2]: sorted uint32 columns, opts {4096, UINT, 2, 1, 1}"})
+        if not args.no_cpu:
+            crow["cpu_baseline"] = cpu_codec_baseline("Cascaded", cols[: 2048 * CHUNK].cpu().numpy())
+        rows.append(crow)
+        del cols
+        res["extra_keys"] = rows
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if dist_on:
+        dist.barrier()
         dist.destroy_process_group()
 
 

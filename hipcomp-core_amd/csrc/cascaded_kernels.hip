@@ -536,11 +536,15 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
     for (int k = 0; k < 8; ++k)
       stage[lane + k * kWave] = pf[k];
     const uint32_t csz = uniform(meta[0]);
-    if (csz == 0) {
+    // A sub-chunk has to lie inside the partition and to move the cursor on:
+    // with csz in 1..3 the reference's cursor (:1412-1413) stands still, and a
+    // sub-chunk that also decodes to zero elements would then be read forever;
+    // a huge csz wraps the 32-bit cursor backwards.
+    if (csz < 4 || csz > comp_bytes - pos) {
       ok = false;
       break;
     }
-    const uint32_t next_pos = ru(pos + (csz / 4) * 4, S); // reference :1412-1413
+    const uint32_t next_pos = ru(pos + (csz / 4) * 4, S); // reference :1412-1413; <= comp_bytes + S: no wrap
     if (next_pos / 4 < end_w)
       prefetch(next_pos);
     // array offsets inside the chunk (reference :1291-1305)

@@ -364,6 +364,10 @@ int oracle_cascaded_decompress(
     if ((pos + (size_t)msz) / 4 > end_w) { ok = 0; break; }
     uint32_t meta[16];
     memcpy(meta, comp + pos, (size_t)(4 * (R + 2)));
+    /* A sub-chunk must lie inside the partition and move the cursor on: with
+     * meta[0] in 1..3 the reference's cursor (:1412-1413) stands still and a
+     * sub-chunk that decodes to zero elements would be read forever. */
+    if (meta[0] < 4 || meta[0] > comp_bytes - pos) { ok = 0; break; }
     size_t offs[16];
     offs[0] = 0;
     if (R > 0) {
@@ -415,7 +419,6 @@ int oracle_cascaded_decompress(
     for (long i = 0; i < n; ++i)
       st(out + (done + (size_t)i) * (size_t)s, x[i], s);
     done += (size_t)n;
-    if (meta[0] == 0) { ok = 0; break; }                 /* no progress: corrupt */
     pos = ru(pos + (meta[0] / 4) * 4, (size_t)s);        /* :1412-1413 */
   }
   if (done != N) ok = 0;                                 /* :1417-1422 */

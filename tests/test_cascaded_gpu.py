@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import datagen
-from test_cascaded_oracle_cpu import NP, _predefined, _sorted_column
+from test_cascaded_oracle_cpu import NP, _predefined, _sorted_column, no_progress_streams
 
 pytestmark = pytest.mark.gpu
 
@@ -97,7 +97,7 @@ def test_decoder_error_paths_match_oracle(hc, oracle, cuda):
     bad_type = bytearray(good); bad_type[3] = 9
     bad_size = bytearray(good); bad_size[4:8] = (len(data) + 400).to_bytes(4, "little")
     streams = [good, good[:-8], good[:40], good[:4], b"", raw, raw[:-4], bytes(bad_type), bytes(bad_size),
-               good[:8] + b"\x00" * 64]
+               good[:8] + b"\x00" * 64] + no_progress_streams()
     for cap in (len(data), len(data) - 4, len(data) + 1000):
         comp = hc.batch.from_host_chunks(streams, "cuda:0")
         dec, actual, statuses = hc.batch.Codec("Cascaded").decompress(comp, cap)

@@ -107,3 +107,26 @@ def test_trailing_partial_element_is_dropped(oracle):
     comp, _ = oracle.cascaded_compress(data, 5, 2, 1, 1)
     assert oracle.cascaded_decompressed_size(comp) == 400
     assert oracle.cascaded_decompress(comp, 402) == (0, data[:400])
+
+
+def no_progress_streams():
+    """Corrupt partitions whose sub-chunk size field would leave the decoder's
+    cursor where it is (1..3), or wrap it backwards (huge), while the
+    sub-chunk itself decodes to zero elements (endless loop)."""
+    out = []
+    for csz in (1, 2, 3, 0xFFFFFFF0, 0x80000000):
+        # R=0, D=0, bp=1, UINT; sub-chunk = [csz][final_bytes] + bit-packed array of 0 elements
+        out.append(struct.pack("<4BI", 0, 0, 1, 5, 16) + struct.pack("<II", csz, 8) + struct.pack("<II", 0, 0))
+        # R=1, D=0, bp=0: one run of length 0 -> zero elements
+        out.append(struct.pack("<4BI", 1, 0, 0, 5, 4) + struct.pack("<III", csz, 2, 4)
+                   + struct.pack("<HH", 0, 0) + struct.pack("<I", 7))
+    return out
+
+
+@pytest.mark.timeout(60)
+def test_sub_chunk_without_progress_is_rejected(oracle):
+    for s in no_progress_streams():
+        assert oracle.cascaded_decompress(s, 4096) == (12, b"")
+    # the same layouts with an honest size field still decode (to nothing / fail on the count, not hang)
+    ok = struct.pack("<4BI", 0, 0, 1, 5, 0) + struct.pack("<II", 16, 8) + struct.pack("<II", 0, 0)
+    assert oracle.cascaded_decompress(ok, 4096) == (0, b"")

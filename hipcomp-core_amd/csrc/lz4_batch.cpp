@@ -126,7 +126,7 @@ hipcompStatus_t hipcompBatchedLZ4CompressAsync(
       reinterpret_cast<const uint8_t* const*>(device_uncompressed_ptrs),
       device_uncompressed_bytes,
       reinterpret_cast<uint8_t* const*>(device_compressed_ptrs),
-      device_compressed_bytes, (uint32_t)ht, batch_size, s, ticket, max_uncompressed_chunk_bytes, stream);
+      device_compressed_bytes, (uint32_t)ht, batch_size, s, ticket, max_uncompressed_chunk_bytes, /*tags=*/true, stream);
   if (e != hipSuccess)
     return fail(fn, std::string("lz4 compress launch: ") + hipGetErrorString(e));
   std::string why;

@@ -8,21 +8,33 @@
 //   --------------------------------------  ---------------------------------
 //   32 KiB hash table per chunk in HBM      table in LDS (ds_read_u16 /
 //   (temp space), global_store_short        ds_write_b16); temp space unused
-//   warpMatchAny = 64-step LDS loop, twice  in-window duplicate search through
-//   per window (:218-245)                   the hash table itself: lane ids
-//                                           posted in reversed lane order, one
-//                                           read-back + one ds_bpermute, exact
-//                                           fallback only for colliding lanes
+//   every table candidate is verified by    a second LDS table holds 8 more
+//   a 4-byte gather from the input (a       hash bits of the word each entry
+//   64-line gather per window: the memory   was made from; a candidate whose
+//   pipe's bound, scripts/probes/           tag differs cannot match and is
+//   gather_rate.hip)                        not fetched
+//   warpMatchAny = 64-step LDS loop, twice  in-window duplicates: found through
+//   per window (:218-245)                   the table itself (one-window path:
+//                                           lane ids posted in reversed lane
+//                                           order; walk: a lane that does not
+//                                           read back its own insert shares a
+//                                           slot), exact compare only for
+//                                           those lanes
 //   second warpMatchAny for the insert      insert rule (incl. the wave64
 //   (:722-741) + hardware arbitration of    `int` truncation)
-//   same-address global_store_short         expressed as ONE lane-permuted masked
-//                                           LDS store (see insert_image)
+//   same-address global_store_short         = ONE masked LDS store with the
+//                                           lanes in priority order ("sigma
+//                                           order", see sigma_of_lane)
+//   one window at a time                    match-less stretches: blocks of
+//                                           windows, all LDS traffic of a block
+//                                           issued back to back, decisions one
+//                                           block later (walk_*)
 //   shuffleLiterals (:754-791)              one unaligned dword load per lane
 //   1 byte/lane literal + match compare     16-byte/lane copies, 4-byte/lane
 //                                           match-length compare
 //
-// One chunk per wavefront (64-thread workgroup): the window loop is a serial
-// dependency chain, the 64 lanes are the 64 window positions.
+// One chunk per wavefront: the window loop is a serial dependency chain, the
+// 64 lanes are the 64 window positions.
 //
 // Decoder: reference src/LZ4Kernels.hiph:971-1097 decompressStream.
 
@@ -38,11 +50,23 @@ namespace {
 
 constexpr uint32_t kNullOffset = 0xFFFFu;
 
+// The walk (see walk_step): windows per block, and how many windows without a
+// match in a row start it.
+constexpr int kLz4WalkBlock = 4;
+constexpr int kLz4WalkAfter = 2;
+
 
 __device__ __forceinline__ uint32_t hash_sum(uint32_t key)
 {
   // reference hash() :557-561 before masking
   return __brev(key) + (key ^ 0xc375u);
+}
+
+// 8 bits of the hash that take no part in the slot number (tables have at
+// most 2^14 slots): the tag of a table entry.
+__device__ __forceinline__ uint32_t tag_of(uint32_t hsum)
+{
+  return (hsum >> 14) & 0xFFu;
 }
 
 // Write `n` in LZ4's linear small-integer code: n/255 bytes of 0xFF then
@@ -63,15 +87,6 @@ __device__ __forceinline__ uint32_t write_sequence(
     gptr comp, uint32_t c, cgptr lit_src, uint32_t lit_bytes,
     uint32_t match_bytes, uint32_t offset_bytes, int lane)
 {
-#ifdef HC_ABL_NO_STORES
-  {
-    uint32_t cc = c + 1;
-    if (lit_bytes >= 15) cc += (lit_bytes - 15u) / 255u + 1u;
-    cc += lit_bytes;
-    if (match_bytes > 0) { cc += 2; if (match_bytes >= 19) cc += (match_bytes - 19u) / 255u + 1u; }
-    return cc;
-  }
-#endif
   if (lane == 0) {
     const uint32_t lh = lit_bytes >= 15 ? 15u : lit_bytes;
     const uint32_t mh = match_bytes >= 19 ? 15u : ((match_bytes - 4u) & 0x0fu);
@@ -95,6 +110,67 @@ __device__ __forceinline__ uint32_t write_sequence(
 }
 
 // ---------------------------------------------------------------------------
+// The two LDS tables of one chunk.
+//   pos[h]  element position & 0xFFFF of the entry, 0xFFFF = empty (the
+//           reference's table, :157, :736)
+//   tag[h]  tag_of() the word the entry was made from.  A candidate matches
+//           only if its 4 bytes equal the window word, which implies equal
+//           tags -- so an entry whose tag differs is rejected without
+//           fetching the candidate's bytes.  Holds while a slot's position
+//           names the element it was made from, i.e. for chunks of at most
+//           65536 elements (`filter`); beyond that the 16-bit position may
+//           alias an element 65536 further on and every candidate is fetched
+//           as in the reference.
+// Both tables are written by the same lanes under the same mask in the same
+// lane order, so they stay entry for entry in step (ds_write_b8 and
+// ds_write_b16 resolve same-address lanes alike: tests/test_hw_probes.py).
+// ---------------------------------------------------------------------------
+template <bool TAGS>
+struct Tables
+{
+  static constexpr bool tags = TAGS; // a tag table exists (a launch-wide choice, lz4_launch_compress)
+  uint16_t* pos;
+  uint8_t* tag;     // valid only with TAGS
+  uint32_t pos_lds; // LDS byte addresses of the two
+  uint32_t tag_lds;
+  bool filter;      // the tags may be used to reject candidates of this chunk
+};
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p)
+{
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)p;
+}
+
+// pos[hpos] = pval, tag[hpos] = tval for the lanes of `mask` (a scalar lane
+// mask: no per-lane flag, no compare), as ONE instruction group.
+template <class TT>
+__device__ __forceinline__ void tables_store_masked(
+    const TT& T, uint32_t hpos, uint32_t pval, uint32_t tval, uint64_t mask)
+{
+  const uint32_t pa = T.pos_lds + 2u * hpos;
+  uint64_t saved;
+  if (T.tags) {
+    const uint32_t ta = T.tag_lds + hpos;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_and_b64 exec, %0, %1\n\t"
+                 "ds_write_b16 %2, %3\n\t"
+                 "ds_write_b8 %4, %5\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "s"(mask), "v"(pa), "v"(pval), "v"(ta), "v"(tval)
+                 : "memory", "scc");
+  } else {
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_and_b64 exec, %0, %1\n\t"
+                 "ds_write_b16 %2, %3\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "s"(mask), "v"(pa), "v"(pval)
+                 : "memory", "scc");
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Hash-table insert for lanes [0, n) of the window at element position d,
 // reproducing what the reference's insertHashTableWarp (:722-741) does when
 // it runs 64 lanes wide:
@@ -112,93 +188,77 @@ __device__ __forceinline__ uint32_t write_sequence(
 //              for q in 0..3: lane 16g+4q+p,  last write survives.
 //
 // Mechanism here: ds_write_b16 keeps the HIGHEST lane among lanes that hit
-// one address (measured, same test), so the whole rule is ONE store whose
-// lanes are permuted (ds_bpermute) into priority order:
+// one address (measured, same test), so the whole rule is ONE masked store
+// once the window lanes sit in the physical lanes in priority order
+// ("sigma order": physical lane p carries window lane sigma(p)):
 //   physical lanes  0..31: window lanes >= 32 in the hardware's write order
 //                          above (the reference's global_store_short);
 //   physical lanes 32..63: window lanes 0..31 in natural order -- they
 //                          override the first half wherever a slot also has
 //                          a window lane below 32.
-// What travels through the permute is the "insert image" of a window lane:
-// bits 0..15 the value, bits 16..29 the slot, bit 31 "this lane stores".
+// In that order window lane 31 is physical lane 63 and window lane 63 is
+// physical lane 19.  The walk loads its window words in sigma order straight
+// from memory; the one-window path permutes them (one ds_bpermute).
 // ---------------------------------------------------------------------------
-constexpr uint32_t kImageStore = 1u << 31;
-
-__device__ __forceinline__ int make_insert_perm_addr4(int lane)
+__device__ __forceinline__ uint32_t sigma_of_lane(int lane)
 {
-  uint32_t src;
-  if (lane < 32) {
-    const uint32_t r = (uint32_t)lane;
-    src = 32u + (r & 16u) + 4u * (r & 3u) + (3u - ((r >> 2) & 3u));
+  const uint32_t r = (uint32_t)lane;
+  return lane < 32 ? 32u + (r & 16u) + 4u * (r & 3u) + (3u - ((r >> 2) & 3u)) : r - 32u;
+}
+
+constexpr uint64_t kSigmaLane31 = 1ull << 63; // physical lane of window lane 31
+constexpr uint64_t kSigmaLane63 = 1ull << 19; // physical lane of window lane 63
+
+// Lanes that store when the first n >= 32 window lanes are inserted; `below`
+// = physical lanes whose window lane is < n, hpos in sigma order.  Also hands
+// back the lanes that share window lane 31's slot.
+__device__ __forceinline__ uint64_t sigma_store_mask(uint32_t hpos, uint64_t below, bool n_is_64, uint64_t& in31)
+{
+  const uint32_t h31 = read_lane(hpos, 63);
+  in31 = wave_ballot(hpos == h31); // includes physical lane 63 itself
+  return (below & ~in31) | (n_is_64 ? kSigmaLane63 : 0ull);
+}
+
+// Insert of the first n >= 32 window lanes of the window at d; word_sigma =
+// the window words in sigma order.
+template <class TT>
+__device__ __forceinline__ void insert_sigma(
+    const TT& T, uint32_t word_sigma, uint32_t d, int n, uint32_t sig, uint32_t hmask)
+{
+  const uint32_t hs = hash_sum(word_sigma);
+  const uint32_t hp = hs & hmask;
+  uint64_t in31;
+  const uint64_t store = sigma_store_mask(hp, wave_ballot(sig < (uint32_t)n), n == 64, in31);
+  tables_store_masked(T, hp, (d + sig) & 0xFFFFu, tag_of(hs), store);
+}
+
+// table lookups of the one-window path and the ds_bpermute that mirrors the
+// slots issued back to back, ONE wait for all (left to itself the compiler
+// waits for the reads first, then issues the permute)
+template <class TT>
+__device__ __forceinline__ void lds_lookup_with_bpermute(
+    const TT& T, uint32_t hpos, int bp_addr4, uint32_t bp_data,
+    uint32_t& slot_value, uint32_t& tag_value, uint32_t& bp_value)
+{
+  const uint32_t pa = T.pos_lds + 2u * hpos;
+  if (T.tags) {
+    const uint32_t ta = T.tag_lds + hpos;
+    asm volatile("ds_read_u16 %0, %3\n\tds_read_u8 %1, %4\n\tds_bpermute_b32 %2, %5, %6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(slot_value), "=&v"(tag_value), "=&v"(bp_value)
+                 : "v"(pa), "v"(ta), "v"(bp_addr4), "v"(bp_data)
+                 : "memory");
   } else {
-    src = (uint32_t)lane - 32u;
+    tag_value = 0;
+    asm volatile("ds_read_u16 %0, %2\n\tds_bpermute_b32 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(slot_value), "=&v"(bp_value)
+                 : "v"(pa), "v"(bp_addr4), "v"(bp_data)
+                 : "memory");
   }
-  return (int)(src * 4u);
-}
-
-// Insert image of this window lane for an insert of the first n >= 32 window
-// lanes.  restore31: lane 31's slot keeps its old content under the rule, so
-// lane 31 can carry that old content (slot_old) instead -- used to undo the
-// duplicate-search marker of that slot in the same store.
-template <int NVMAX>
-__device__ __forceinline__ uint32_t insert_image(
-    uint32_t hpos, uint32_t pos, uint32_t slot_old, int n, int lane, bool restore31)
-{
-  // The rule as lane masks (scalar): lanes 0..30 and 32..n-1 store unless
-  // they share lane 31's slot; lane 63 of a full 64-lane window stores in
-  // any case; lane 31 stores (the old content) only to undo a marker, and
-  // not if lane 63 overwrites that slot anyway.
-  const uint32_t h31 = read_lane(hpos, 31);
-  const uint64_t in31 = wave_ballot(hpos == h31);
-  const uint64_t unless31 = lanes_below<NVMAX>(n) & ~(1ull << 31);
-  uint64_t always = 0;
-  if (NVMAX == 64 && n == 64) {
-    always = 1ull << 63;
-    if (in31 >> 63)
-      restore31 = false;
-  }
-  if (restore31)
-    always |= 1ull << 31;
-  const uint64_t store = always | (unless31 & ~in31);
-  uint32_t flag;
-  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(flag) : "v"(kImageStore), "s"(store));
-  const uint32_t value = lane == 31 ? slot_old : pos; // 16 bits each
-  return (hpos << 16) | flag | value;
-}
-
-__device__ __forceinline__ void store_insert_image(uint16_t* table, uint32_t image)
-{
-  if ((int32_t)image < 0)
-    table[(image >> 16) & 0x3FFFu] = (uint16_t)image;
-}
-
-// n <= 31: plain store of the first n lanes.
-__device__ __forceinline__ void insert_short_window(
-    uint16_t* table, uint32_t hpos, uint32_t pos, int n, int lane)
-{
-  if (lane < n)
-    table[hpos] = (uint16_t)pos;
-}
-
-// table[slot] and ds_bpermute issued back to back, ONE wait for both (left to
-// itself the compiler waits for the read, then issues the permute).
-__device__ __forceinline__ void lds_read_u16_with_bpermute(
-    const uint16_t* slot, int bp_addr4, uint32_t bp_data, uint32_t& slot_value, uint32_t& bp_value)
-{
-  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t*)slot;
-  asm volatile("ds_read_u16 %0, %2\n\tds_bpermute_b32 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(slot_value), "=&v"(bp_value)
-               : "v"(a), "v"(bp_addr4), "v"(bp_data)
-               : "memory");
 }
 
 // ---------------------------------------------------------------------------
 // One window of the match search = 64 consecutive element positions, one per
-// lane (reference :847-962).  Its work comes in two halves:
-//   table half    hash, table lookup, candidate verification load, search
-//                 markers, table insert;
-//   decision half first lane with a match (in-window duplicate or verified
-//                 table candidate).
+// lane (reference :847-962), in natural lane order: the one-window path.
 // ---------------------------------------------------------------------------
 struct Window
 {
@@ -207,14 +267,14 @@ struct Window
   bool valid;         // lane < nv
   uint32_t word;      // the 4 bytes at element d + lane
   uint32_t hpos;      // my table slot
+  uint32_t tag;       // my word's tag
   uint32_t h_old;     // what the slot held before this window
+  uint32_t t_old;     // ... and its tag
   uint32_t cand;      // element the slot points to
   uint64_t probe;     // lanes whose candidate is usable: its word gets verified (uniform)
   uint32_t cand_word; // 4 bytes at cand (in flight until first use)
-  uint32_t next_word; // 4 bytes at element d + nv + lane, in the pipelined walk
-                      // at d + 2 nv + lane (in flight)
+  uint32_t next_word; // 4 bytes at element d + nv + lane (in flight)
   uint32_t w_raw;     // marker read back from my slot: lowest lane in it
-  uint32_t pimage;    // lane-permuted insert image of the whole window
 };
 
 struct Decision
@@ -224,17 +284,18 @@ struct Decision
   uint32_t match_location; // element it matches
 };
 
-// FULL: the caller knows that the window has all NVMAX lanes.
-template <int S, int NVMAX, bool FULL = false>
+template <int S, int NVMAX>
 __device__ __forceinline__ void window_begin(
     Window& W, uint32_t d, uint32_t word, uint32_t L, uint32_t hmask, int lane)
 {
   constexpr uint32_t LVM = (12 + S - 1) / S;
   W.d = d;
-  W.nv = FULL ? NVMAX : min(NVMAX, (int)(L - d - LVM)); // >= 1
+  W.nv = min(NVMAX, (int)(L - d - LVM)); // >= 1
   W.valid = lane < W.nv;
   W.word = word;
-  W.hpos = hash_sum(word) & hmask;
+  const uint32_t hs = hash_sum(word);
+  W.hpos = hs & hmask;
+  W.tag = tag_of(hs);
 }
 
 // (B) candidate from earlier windows (reference isValidHash :634-663,
@@ -242,11 +303,9 @@ __device__ __forceinline__ void window_begin(
 // window's words: the latter is issued AFTER the verify so that waiting for the
 // verify (in-order vmcnt) does not wait for it.  Both loads are unconditional
 // with a clamped, always readable index so that the compiler can count them.
-// FULL: a full window follows this one, so every lane's own position is a
-// readable word and needs no clamp.
-template <int S, bool FULL = false>
+template <int S, class TT>
 __device__ __forceinline__ void window_candidate(
-    Window& W, cgptr in, uint32_t last_word, int lane, bool load_next = true, int ahead = 1)
+    Window& W, const TT& T, cgptr in, uint32_t last_word, int lane, bool load_next)
 {
   const uint32_t pos = W.d + (uint32_t)lane;
   // The slot holds the low 16 bits of an element before pos: the candidate
@@ -259,26 +318,22 @@ __device__ __forceinline__ void window_candidate(
   // whose byte distance does not fit are rejected here; for chunks
   // <= 64 KiB this never triggers, so those stay bit-identical
   // (DESIGN.md "deliberate deviations").
-#ifdef HC_ABL_NO_VERIFY
-  W.probe = 0;
-#else
   // (one ballot per compare, combined as scalars: a ballot of the combined
   // per-lane condition goes through a VGPR)
   W.probe = wave_ballot(W.h_old != kNullOffset) & wave_ballot(back < 65535u / S)
             & lanes_below<64>(W.nv);
-#endif
+  if (T.filter)
+    W.probe &= wave_ballot(W.t_old == W.tag);
   W.cand = cand;
-  const uint32_t own = FULL ? pos : min(pos, last_word);
+  const uint32_t own = min(pos, last_word);
   uint32_t at; // probe ? cand : own, straight from the scalar lane mask
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(at) : "v"(own), "v"(cand), "s"(W.probe));
   W.cand_word = load_u32_any(in + (size_t)at * S);
   // Next words: not after a window with a match (this one most likely has
   // one too, the words would be dropped, and a load in flight into a
   // register the match path wants to reuse makes that path wait for it).
-  // The pipelined walk loads two windows ahead: one step of it is shorter
-  // than a trip to HBM.
   if (load_next)
-    W.next_word = load_u32_any(in + (size_t)min(pos + (uint32_t)(ahead * W.nv), last_word) * S);
+    W.next_word = load_u32_any(in + (size_t)min(pos + (uint32_t)W.nv, last_word) * S);
 }
 
 // (A) in-window duplicates: lowest lane holding my word, found through the
@@ -288,33 +343,17 @@ __device__ __forceinline__ void window_candidate(
 // leaves the LOWEST window lane of each slot; reading the slot back names that
 // lane.  If it holds my word it is exactly min{u : word_u == word_t};
 // otherwise two different words share the slot and the lane is settled by the
-// exact fallback in window_decide.
-// The same LDS round trip carries the lane permute of the insert image of a
-// window WITHOUT a match (all nv lanes, reference :958-962); storing that image
-// overwrites every marker but the one of lane 31's slot, whose old content the
-// image carries (insert_image).  Nothing is waited for here.
-// FULL: all NVMAX lanes are valid and `pr` is the plain slot of the mirrored
-// lane -- except that the 64 - NVMAX lanes mirroring the invalid window lanes
-// were handed window lane 0's slot: they post into it unconditionally and
-// always lose to window lane 0 itself (the highest physical lane), so the
-// marker store needs no exec mask.
-template <int NVMAX, bool WITH_IMAGE = true, bool FULL = false>
+// exact fallback in window_decide.  The markers are taken off the table again
+// by window_insert_first (the tag table is not touched by any of this).
+template <class TT>
 __device__ __forceinline__ void window_markers(
-    Window& W, uint16_t* table, uint32_t pr, uint32_t rev_lane, int perm_addr4, int lane)
+    Window& W, const TT& T, uint32_t pr, uint32_t rev_lane)
 {
-  uint32_t image = 0;
-  if (WITH_IMAGE)
-    image = insert_image<NVMAX>(
-        W.hpos, (W.d + (uint32_t)lane) & 0xFFFFu, W.h_old, W.nv, lane, true);
   lds_lane_exchange_fence();
-  if (FULL)
-    table[pr] = (uint16_t)rev_lane;
-  else if (pr & 0x80000000u)
-    table[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
+  if (pr & 0x80000000u)
+    T.pos[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
   lds_lane_exchange_fence();
-  W.w_raw = table[W.hpos];
-  if (WITH_IMAGE)
-    W.pimage = (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)image);
+  W.w_raw = T.pos[W.hpos];
   lds_lane_exchange_fence();
 }
 
@@ -368,51 +407,25 @@ __device__ __forceinline__ Decision window_decide(const Window& W, uint32_t nw, 
   return D;
 }
 
-// False only if window_decide would find no match: every valid lane is alone
-// in its slot (then it has no duplicate and nothing is unresolved) and no
-// table candidate holds its lane's word.
-__device__ __forceinline__ uint64_t window_suspect_lanes(const Window& W, int lane)
-{
-  return wave_ballot(window_winner(W, lane) != (uint32_t)lane)
-         | (wave_ballot(W.cand_word == W.word) & W.probe);
-}
-
-// Table state "only the first f lanes of W were inserted", from any state in
-// which W's slots hold markers or W's full insert.
-template <int NVMAX>
+// Table state "only the first f lanes of W were inserted", from the state in
+// which W's slots hold its markers.
+template <int NVMAX, class TT>
 __device__ __forceinline__ void window_insert_first(
-    const Window& W, uint16_t* table, int f, int perm_addr4, int lane)
+    const Window& W, const TT& T, int f, int perm_addr4, uint32_t sig, uint32_t hmask, int lane)
 {
-  const uint32_t pos16 = (W.d + (uint32_t)lane) & 0xFFFFu;
   if (W.valid)
-    table[W.hpos] = (uint16_t)W.h_old;
+    T.pos[W.hpos] = (uint16_t)W.h_old;
   lds_lane_exchange_fence();
   if (f >= 32) {
-    const uint32_t im = insert_image<NVMAX>(W.hpos, pos16, 0, f, lane, false);
-    store_insert_image(table, (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)im));
-  } else {
-    insert_short_window(table, W.hpos, pos16, f, lane);
+    const uint32_t ws = (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)W.word);
+    insert_sigma(T, ws, W.d, f, sig, hmask);
+  } else if (lane < f) {
+    // n <= 31: the highest lane of a slot stores -- natural lane order
+    T.pos[W.hpos] = (uint16_t)(W.d + (uint32_t)lane);
+    if (T.tags)
+      T.tag[W.hpos] = (uint8_t)W.tag;
   }
-}
-
-// The same group without the wait, and the wait as a separate statement that
-// hands the two results on: whatever is written between the two runs in the
-// shadow of the LDS round trip.  `done_first` is a scalar the caller wants
-// computed BEFORE the wait (it pins that computation above it; without the
-// operand the compiler may sink it below).
-__device__ __forceinline__ void lds_read_u16_with_bpermute_issue(
-    const uint16_t* slot, int bp_addr4, uint32_t bp_data, uint32_t& slot_value, uint32_t& bp_value)
-{
-  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t*)slot;
-  asm volatile("ds_read_u16 %0, %2\n\tds_bpermute_b32 %1, %3, %4"
-               : "=&v"(slot_value), "=&v"(bp_value)
-               : "v"(a), "v"(bp_addr4), "v"(bp_data)
-               : "memory");
-}
-
-__device__ __forceinline__ void lds_wait_for(uint32_t& slot_value, uint32_t& bp_value, uint64_t done_first)
-{
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(slot_value), "+v"(bp_value) : "s"(done_first) : "memory");
+  lds_lane_exchange_fence();
 }
 
 // First mismatching element between the strings at elements `prev` and `pos`
@@ -459,65 +472,280 @@ __device__ __forceinline__ uint32_t match_length(
   return limit;
 }
 
-// One step of the pipelined walk.  Three windows are in flight: P and Q have
-// had their table half and their insert (on the guess that they have no
-// match), N is the window behind Q.  N's table half runs while P's
-// verification load -- issued two steps ago -- is in its last stretch; P's
-// decision is then, nearly always, one cheap test.
-//   kWalkOn     P had no match; Q, N and the next window move up
-//   kWalkMatch  P has the match D; N's markers and Q's insert are off the
-//               table again, P's full insert still has to be cut back
-//               (window_insert_first)
-//   kWalkDrain  P had no match and no full window follows N: N is inserted,
-//               Q and N are still to be decided, in this order
-constexpr int kWalkOn = 0, kWalkMatch = 1, kWalkDrain = 2;
-
-// Puts back what W's slots held before W (its markers or its insert).
-__device__ __forceinline__ void window_undo(const Window& W, uint16_t* table)
+// ---------------------------------------------------------------------------
+// The walk: a stretch of windows without a match (incompressible data) taken
+// a BLOCK of G full windows at a time, in sigma order.  Nothing in a window's
+// table traffic depends on what the table returns -- lookup, insert (on the
+// guess that the window has no match) and the read-back of the insert depend
+// on the window's words only -- so the 5 G LDS operations of a block are
+// issued back to back (LDS operations of a wave execute in order) and cost
+// their issue slots, not their latency.  What the lookups return is looked at
+// one block later:
+//   * a lane whose read-back is not its own position shares its slot with
+//     another lane of the window: the only lanes that can be one half of an
+//     in-window duplicate (equal words hash alike and only one lane per slot
+//     reads itself back).  Nearly always there is none; else exact compare.
+//   * a lane whose slot held an entry with its word's tag: its candidate is
+//     fetched (about one lane in four windows on random data, instead of a
+//     64-line gather per window) and compared one block later.
+// A window that does have a match ends the walk: the inserts of all younger
+// windows and its own are taken back (newest first, from the kept old slot
+// contents) and the one-window path redoes it.
+// ---------------------------------------------------------------------------
+template <int G>
+struct WalkBlock
 {
-  if (W.valid)
-    table[W.hpos] = (uint16_t)W.h_old;
-  lds_lane_exchange_fence();
+  uint32_t word[G];      // sigma order
+  uint32_t hpos[G];
+  uint16_t h_old[G];     // (kept as narrow as the tables hold them: a widening here makes the
+  uint8_t t_old[G];      //  compiler wait for the lookup in the step that issued it)
+  uint16_t rb[G];        // my slot after the window's insert
+  uint64_t tprobe[G];    // lanes whose candidate was fetched (uniform)
+  uint64_t l31_sharers;  // valid lanes that share window lane 31's slot, all windows of the block together (uniform)
+};
+
+// A 16- or 8-bit table entry as a full register: hides from the compiler that
+// the upper bits are zero (knowing it, it narrows some users to 16-bit
+// compares, reads the entry "any-extended" and then masks it for the others).
+__device__ __forceinline__ uint32_t as_full_register(uint32_t v)
+{
+  asm("" : "+v"(v));
+  return v;
 }
 
-template <int S, int NVMAX>
-__device__ __forceinline__ int walk_step(
-    const Window& P, const Window& Q, Window& N, Decision& D, uint16_t* table, cgptr in,
-    uint32_t L, uint32_t last_word, uint32_t hmask, uint32_t rev_lane, int rev_addr4_full,
-    int perm_addr4, int lane)
+// The walk's loads are issued and awaited by hand, and they land in
+// ACCUMULATION registers (AGPRs), which the compiler does not allocate:
+//  * vector memory operations complete in issue order and `s_waitcnt
+//    vmcnt(N)` waits for all but the N youngest; a step issues exactly G
+//    candidate loads, then G word loads, so the counts are known.  The
+//    compiler's own counting gives up on the walk's control flow (it waited
+//    for the words loaded two blocks ahead at every step: a trip to HBM);
+//  * a value in flight must not be touched before its wait.  In compiler-
+//    allocated registers that cannot be promised (it may move a register
+//    that an asm statement is about to wait for); an AGPR named in the asm
+//    text is out of its reach.  After the wait the value is read into a
+//    normal register (v_accvgpr_read_b32) and is the compiler's from there.
+// Slots: words of block b in a[4 (b % 3) ..], its candidate words in
+// a[12 + 4 (b % 3) ..].
+#define HC_WALK_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", \
+                      "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23"
+
+template <int A>
+__device__ __forceinline__ void agpr_load_u32(cgptr base, uint32_t byte_off)
 {
-  constexpr uint32_t LVM = (12 + S - 1) / S;
-  uint32_t prN;
-  // every window loads the words of the window two behind it: N's are P's
-  window_begin<S, NVMAX, true>(N, Q.d + (uint32_t)NVMAX, P.next_word, L, hmask, lane);
-  lds_read_u16_with_bpermute_issue(table + N.hpos, rev_addr4_full, N.hpos, N.h_old, prN);
-  // in the shadow of that LDS round trip: P's test (below)
-  const uint64_t suspect = window_suspect_lanes(P, lane);
-  lds_wait_for(N.h_old, prN, suspect);
-  window_candidate<S, true>(N, in, last_word, lane, true, 2);
-  window_markers<NVMAX, true, true>(N, table, prN, rev_lane, perm_addr4, lane);
-  // Nearly always P has no slot shared by two lanes (so neither a duplicate
-  // nor anything for the exact fallback) and no verified candidate: one test
-  // for all of that (and for "N is the last full window") instead of the
-  // full decision.  A taken branch costs a lone wave ~24 cycles, an untaken
-  // one ~10 (scripts/probes/branch_cost.hip).
-  const bool last = (int)(L - N.d - LVM) < 2 * NVMAX;
-  if (__builtin_expect((suspect != 0) | last, 0)) {
-    const uint32_t nwP = (uint32_t)__builtin_amdgcn_ds_bpermute(
-        (int)(window_winner(P, lane) * 4u), (int)P.word);
-    D = window_decide<NVMAX>(P, nwP, lane);
-    if (D.match) {
-      window_undo(N, table); // newest first: N read its slots after Q's insert
-      window_undo(Q, table);
-      return kWalkMatch;
+  asm volatile("global_load_dword a[%2], %0, %1" : : "v"(byte_off), "s"(base), "n"(A) : HC_WALK_AGPRS);
+}
+
+// waits until at most N younger loads are in flight, then a[A0 .. A0+3] -> r
+template <int A0, int N>
+__device__ __forceinline__ void agpr_take4(uint32_t (&r)[4])
+{
+  asm volatile("s_waitcnt vmcnt(%4)\n\t"
+               "v_accvgpr_read_b32 %0, a[%5]\n\t"
+               "v_accvgpr_read_b32 %1, a[%6]\n\t"
+               "v_accvgpr_read_b32 %2, a[%7]\n\t"
+               "v_accvgpr_read_b32 %3, a[%8]"
+               : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3])
+               : "n"(N), "n"(A0), "n"(A0 + 1), "n"(A0 + 2), "n"(A0 + 3));
+}
+
+// issues the loads of the words of the G windows from element d0 on into
+// slot R; CLAMP: the block may reach past the last full window (it is loaded
+// ahead of knowing), keep the loads readable
+template <int S, int G, bool CLAMP, int R>
+__device__ __forceinline__ void walk_load(cgptr in, uint32_t d0, uint32_t sig, uint32_t last_word)
+{
+  static_assert(G == 4, "slot layout");
+  constexpr int NVMAX = kWave - 3 / S;
+  uint32_t e[G];
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    e[k] = d0 + (uint32_t)(k * NVMAX) + sig;
+    if (CLAMP)
+      e[k] = min(e[k], last_word);
+  }
+  agpr_load_u32<4 * R + 0>(in, e[0] * (uint32_t)S);
+  agpr_load_u32<4 * R + 1>(in, e[1] * (uint32_t)S);
+  agpr_load_u32<4 * R + 2>(in, e[2] * (uint32_t)S);
+  agpr_load_u32<4 * R + 3>(in, e[3] * (uint32_t)S);
+}
+
+// table traffic of a block: lookup, insert, read-back per window, no waits
+template <int S, int G, class TT>
+__device__ __forceinline__ void walk_tables(
+    WalkBlock<G>& B, const TT& T, uint32_t d0, uint32_t sig, uint32_t hmask, uint64_t validc)
+{
+  constexpr int NVMAX = kWave - 3 / S;
+  uint64_t sharers = 0;
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    const uint32_t hs = hash_sum(B.word[k]);
+    const uint32_t hp = hs & hmask;
+    B.hpos[k] = hp;
+    uint64_t in31;
+    const uint64_t store = sigma_store_mask(hp, validc, NVMAX == 64, in31);
+    sharers |= in31;
+    B.h_old[k] = T.pos[hp];
+    if (T.tags)
+      B.t_old[k] = T.tag[hp];
+    lds_lane_exchange_fence();
+    tables_store_masked(T, hp, (d0 + (uint32_t)(k * NVMAX) + sig) & 0xFFFFu, tag_of(hs), store);
+    B.rb[k] = T.pos[hp];
+    lds_lane_exchange_fence();
+  }
+  B.l31_sharers = sharers & validc & ~kSigmaLane31;
+}
+
+// What the lookups of a block returned: the candidates that cannot be ruled
+// out are fetched.  ONE load per window whatever the data (lanes without a
+// candidate re-read their own window word, a line that is in L1), so that the
+// loads in flight can be counted.
+template <int S, int G, int R, class TT>
+__device__ __forceinline__ void walk_probe(
+    WalkBlock<G>& B, const TT& T, cgptr in, uint32_t d0, uint32_t sig, uint64_t validc)
+{
+  constexpr int NVMAX = kWave - 3 / S;
+  const uint64_t unfiltered = T.filter ? 0ull : ~0ull;
+  uint32_t at[G]; // tprobe ? candidate : own position
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    const uint32_t pos = d0 + (uint32_t)(k * NVMAX) + sig;
+    const uint32_t h_old = as_full_register(B.h_old[k]);
+    const uint32_t back = (pos - 1u - h_old) & 0xFFFFu;
+    uint64_t tp = wave_ballot(h_old != kNullOffset) & wave_ballot(back < 65535u / S) & validc; // see window_candidate
+    if (TT::tags)
+      tp &= wave_ballot(as_full_register(B.t_old[k]) == tag_of(hash_sum(B.word[k]))) | unfiltered;
+    B.tprobe[k] = tp;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(at[k]) : "v"(pos), "v"(pos - 1u - back), "s"(tp));
+  }
+  agpr_load_u32<12 + 4 * R + 0>(in, at[0] * (uint32_t)S);
+  agpr_load_u32<12 + 4 * R + 1>(in, at[1] * (uint32_t)S);
+  agpr_load_u32<12 + 4 * R + 2>(in, at[2] * (uint32_t)S);
+  agpr_load_u32<12 + 4 * R + 3>(in, at[3] * (uint32_t)S);
+}
+
+// first window of the block that has a match, G if none
+template <int S, int G>
+__device__ __forceinline__ int walk_decide(
+    const WalkBlock<G>& B, const uint32_t (&cand_word)[G], uint32_t d0, uint32_t sig, uint64_t validc)
+{
+  constexpr int NVMAX = kWave - 3 / S;
+  uint64_t tm[G], fl[G];
+  uint64_t any = 0;
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    const uint32_t pos16 = (d0 + (uint32_t)(k * NVMAX) + sig) & 0xFFFFu;
+    tm[k] = wave_ballot(cand_word[k] == B.word[k]) & B.tprobe[k];
+    // a lane that does not read back its own insert shares its slot; window
+    // lane 31 never stores (for it the test says nothing), it takes part iff
+    // another lane is in its slot
+    fl[k] = wave_ballot(as_full_register(B.rb[k]) != pos16) & validc & ~kSigmaLane31;
+    any |= tm[k] | fl[k];
+  }
+  if (__builtin_expect((any | B.l31_sharers) == 0, 1))
+    return G;
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    if (tm[k])
+      return k;
+    uint64_t U = fl[k];
+    if (B.l31_sharers) { // (rare) is it this window in which window lane 31 has company?
+      const uint64_t in31 = wave_ballot(B.hpos[k] == read_lane(B.hpos[k], 63)) & validc & ~kSigmaLane31;
+      if (in31)
+        U |= kSigmaLane31;
     }
-    if (last) {
-      store_insert_image(table, N.pimage);
-      return kWalkDrain;
+    while (U) { // exact: does a slot sharer hold the word of another lane?
+      const int u = __builtin_ctzll(U);
+      U &= U - 1;
+      const uint32_t v = read_lane(B.word[k], u);
+      const uint64_t m = wave_ballot(B.word[k] == v) & validc;
+      if (m & (m - 1))
+        return k;
     }
   }
-  store_insert_image(table, N.pimage);
-  return kWalkOn;
+  return G;
+}
+
+// takes the inserts of windows [from, G) of the block off the tables again,
+// newest first
+template <int G, class TT>
+__device__ __forceinline__ void walk_undo(const WalkBlock<G>& B, const TT& T, int from, uint64_t validc)
+{
+#pragma unroll
+  for (int k = G - 1; k >= 0; --k)
+    if (k >= from)
+      tables_store_masked(T, B.hpos[k], B.h_old[k], B.t_old[k], validc);
+}
+
+// One step of the walk works on three blocks, each in another stage:
+//   p1  (one block back)   its lookups -- a whole step old -- are read and its
+//                          candidates asked for (walk_probe);
+//   cur                    its words, asked for two steps ago, go through the
+//                          tables (walk_tables);
+//   p2  (two blocks back)  its candidate words, asked for a whole step ago,
+//                          decide whether the walk goes on (walk_decide).
+// Order in a step: word loads for the block two ahead, tables of cur, probe
+// of p1, decision about p2 -- so nothing is used before a whole step has
+// passed since it was asked for.  Vector memory operations complete in issue
+// order; a step issues G word loads, then G candidate loads, so behind the
+// words of `cur` WORDS_YOUNGER = 4 G loads have been issued (2 G and 3 G in
+// the first two steps of a walk) and behind the candidate words of p2 2 G.
+// Returns the window of p2 that has a match (the tables are then back in the
+// state before that window), G if none (or no p2 yet).
+template <int S, int G, int RC, int WORDS_YOUNGER, bool HAVE_P2, class TT>
+__device__ __forceinline__ int walk_step(
+    WalkBlock<G>& cur, WalkBlock<G>& p1, WalkBlock<G>& p2, const TT& T, cgptr in, uint32_t d_cur, uint32_t sig,
+    uint32_t hmask, uint32_t last_word, uint64_t validc)
+{
+  constexpr int NVMAX = kWave - 3 / S;
+  constexpr int R1 = (RC + 2) % 3; // slot of p1, and of the block two ahead of cur
+  constexpr int R2 = (RC + 1) % 3; // slot of p2
+  walk_load<S, G, true, R1>(in, d_cur + (uint32_t)(2 * G * NVMAX), sig, last_word);
+  agpr_take4<4 * RC, WORDS_YOUNGER>(cur.word);
+  walk_tables<S, G>(cur, T, d_cur, sig, hmask, validc);
+  walk_probe<S, G, R1>(p1, T, in, d_cur - (uint32_t)(G * NVMAX), sig, validc);
+  if (!HAVE_P2)
+    return G;
+  uint32_t cand_word[G];
+  agpr_take4<12 + 4 * R2, 2 * G>(cand_word);
+  const int j = walk_decide<S, G>(p2, cand_word, d_cur - (uint32_t)(2 * G * NVMAX), sig, validc);
+  if (__builtin_expect(j < G, 0)) {
+    walk_undo<G>(cur, T, 0, validc);
+    walk_undo<G>(p1, T, 0, validc);
+    walk_undo<G>(p2, T, j, validc);
+  }
+  return j;
+}
+
+// End of a walk: x (at element dx, slot RX) has been through the tables, y --
+// the block before it, if any -- has had its candidates asked for.  Decides
+// both, oldest first.  Returns the element of the first window with a match
+// (the tables are back in the state before it), or the element behind x.
+template <int S, int G, int RX, class TT>
+__device__ __forceinline__ uint32_t walk_drain(
+    WalkBlock<G>& x, WalkBlock<G>& y, bool have_y, const TT& T, cgptr in, uint32_t dx, uint32_t sig,
+    uint64_t validc, bool& match)
+{
+  constexpr int NVMAX = kWave - 3 / S;
+  constexpr int RY = (RX + 2) % 3;
+  walk_probe<S, G, RX>(x, T, in, dx, sig, validc);
+  uint32_t cw[G];
+  if (have_y) {
+    agpr_take4<12 + 4 * RY, 0>(cw);
+    const int j = walk_decide<S, G>(y, cw, dx - (uint32_t)(G * NVMAX), sig, validc);
+    if (j < G) {
+      walk_undo<G>(x, T, 0, validc);
+      walk_undo<G>(y, T, j, validc);
+      match = true;
+      return dx - (uint32_t)(G * NVMAX) + (uint32_t)(j * NVMAX);
+    }
+  }
+  agpr_take4<12 + 4 * RX, 0>(cw);
+  const int j = walk_decide<S, G>(x, cw, dx, sig, validc);
+  if (j < G)
+    walk_undo<G>(x, T, j, validc);
+  match = j < G;
+  return dx + (uint32_t)(j * NVMAX);
 }
 
 // The sequence that ends with the match D found in the window at element wd
@@ -569,30 +797,34 @@ __device__ __forceinline__ void emit_match(
 // and `v_readfirstlane` then ran with lane 0 split off (an endless loop).  An
 // unconditional atomic with per-lane addends (1, 0, 0, ...) avoids that but
 // becomes a 64-step serial scan in the compiler's atomic optimizer -- a third
-// of the time of a 1 KiB chunk.
+// of the time of a 1 KiB chunk.  The statement narrows exec to lane 0 of the
+// lanes it was entered with and puts it back (scratch SGPRs are the
+// compiler's choice); it is only ever reached with all 64 lanes active, the
+// small-chunk GPU tests (many tickets per wave) are its regression test.
 __device__ __forceinline__ uint32_t take_ticket(uint32_t* ticket, uint32_t count)
 {
   uint32_t t;
-  const uint32_t zero = 0, one = count;
-  asm volatile("s_mov_b64 s[20:21], exec\n\t"
-               "s_mov_b64 exec, 1\n\t"
-               "global_atomic_add %0, %1, %2, %3 sc0\n\t"
+  uint64_t saved;
+  const uint32_t zero = 0;
+  asm volatile("s_mov_b64 %1, exec\n\t"
+               "s_and_b64 exec, %1, 1\n\t"
+               "global_atomic_add %0, %2, %3, %4 sc0\n\t"
                "s_waitcnt vmcnt(0)\n\t"
-               "s_mov_b64 exec, s[20:21]"
-               : "=&v"(t)
-               : "v"(zero), "v"(one), "s"(ticket)
-               : "s20", "s21", "memory");
+               "s_mov_b64 exec, %1"
+               : "=&v"(t), "=&s"(saved)
+               : "v"(zero), "v"(count), "s"(ticket)
+               : "memory", "scc");
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 }
 
-// Workgroup shape: the hash table (ht_size x u16, 32 KiB for 64 KiB chunks)
-// is the only LDS user and LDS is what limits residency.  The CU allocates
-// LDS in 1280-byte granules, so five separate 32 KiB workgroups do not fit
-// into its 160 KiB (5 x 26 granules) but ONE workgroup of five waves with
-// 5 x 32 KiB does.  Each wave of the workgroup owns one table and takes
-// chunks from a global ticket counter until the batch is exhausted; the waves
-// never synchronise with each other.
-template <int S>
+// Workgroup shape: a chunk's tables (ht_size x (u16 + u8), 48 KiB for 64 KiB
+// chunks; 32 KiB without tags) are the only LDS user and LDS is what limits
+// residency.  The CU allocates LDS in 1280-byte granules, so separate
+// workgroups of one wave each would waste part of its 160 KiB; ONE workgroup
+// of several waves that owns all of it does not.  Each wave of the workgroup
+// owns one pair of tables and takes chunks from a global ticket counter until
+// the batch is exhausted; the waves never synchronise with each other.
+template <int S, bool TAGS>
 __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_kernel(
     const uint8_t* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
@@ -609,18 +841,23 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   constexpr uint32_t LVM = (12 + S - 1) / S; // last valid match, elements
   constexpr int INV = 3 / S;                 // lanes without a full 4-byte word
   constexpr int NVMAX = kWave - INV;
+  constexpr int G = kLz4WalkBlock;
 
   const int lane = lane_id();
   const uint32_t wave = uniform((uint32_t)(threadIdx.x >> 6));
   uint8_t* const my_smem = smem + wave * table_stride;
-  uint16_t* const table = reinterpret_cast<uint16_t*>(my_smem);
   const uint32_t hmask = ht_size - 1;
-  const int perm_addr4 = make_insert_perm_addr4(lane);
+  Tables<TAGS> T;
+  T.pos = reinterpret_cast<uint16_t*>(my_smem);
+  T.tag = my_smem + 2 * ht_size;
+  T.pos_lds = uniform(lds_addr_of(my_smem));
+  T.tag_lds = T.pos_lds + 2 * ht_size;
+  T.filter = false;
+  const uint32_t sig = sigma_of_lane(lane);
+  const int perm_addr4 = (int)(sig * 4u);
+  const uint64_t validc = wave_ballot(sig < (uint32_t)NVMAX); // valid lanes of a full window, sigma order
   const uint32_t rev_lane = 63u - (uint32_t)lane;
   const int rev_addr4 = (int)(rev_lane * 4u);
-  // for full windows: the lanes that mirror the invalid window lanes take
-  // window lane 0's slot instead (window_markers)
-  const int rev_addr4_full = lane < INV ? 0 : rev_addr4;
 
  for (;;) {
   // A ticket is good for chunks_per_ticket consecutive chunks (more than one
@@ -638,8 +875,10 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   const uint32_t len = (uint32_t)in_bytes[chunk];
   gptr __restrict__ out = to_global(out_ptrs[chunk]);
   const uint32_t L = (len + S - 1) / S;
+  T.filter = TAGS && L <= 65536u;
 
-  // ---- LDS init (reference :815-818 fills the table with NULL_OFFSET)
+  // ---- LDS init (reference :815-818 fills the table with NULL_OFFSET); tags
+  // of empty slots are never looked at
   {
     u32x4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     u32x4* p = reinterpret_cast<u32x4*>(my_smem);
@@ -658,86 +897,50 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   uint32_t next = 0;
   if (L > LVM)
     next = load_u32_any(in + (size_t)min((uint32_t)lane, last_word) * S);
-  // the previous window had no match: walk the following ones pipelined
-  bool cold = false;
+  // windows without a match in a row: the walk starts after kLz4WalkAfter
+  int cold = 0;
 
   uint32_t token_start = 0; // first element not yet written out
   while (d < L) {
-    if (cold && (int)(L - d - LVM) >= 3 * NVMAX) {
-      // ---- pipelined walk over match-less full windows (here: three full
-      // windows lie ahead).  A window's insert is done at once, on the guess
-      // that it has no match; its decision follows two windows later, when
-      // its verification load has had two steps to arrive.  A match rolls the
-      // table back and drops the newer windows.
-      Window A, B, C, W; // W: the window the walk ended on
-      Decision D;
-      {
-        uint32_t pr;
-        window_begin<S, NVMAX, true>(A, d, next, L, hmask, lane);
-        lds_read_u16_with_bpermute(table + A.hpos, rev_addr4_full, A.hpos, A.h_old, pr);
-        window_candidate<S, true>(A, in, last_word, lane, true, 2);
-        window_markers<NVMAX, true, true>(A, table, pr, rev_lane, perm_addr4, lane);
-        store_insert_image(table, A.pimage);
-        const uint32_t wordsB = load_u32_any(
-            in + (size_t)min(d + (uint32_t)(NVMAX + lane), last_word) * S);
-        window_begin<S, NVMAX, true>(B, d + (uint32_t)NVMAX, wordsB, L, hmask, lane);
-        lds_read_u16_with_bpermute(table + B.hpos, rev_addr4_full, B.hpos, B.h_old, pr);
-        window_candidate<S, true>(B, in, last_word, lane, true, 2);
-        window_markers<NVMAX, true, true>(B, table, pr, rev_lane, perm_addr4, lane);
-        store_insert_image(table, B.pimage);
+    if (cold >= kLz4WalkAfter && (int)(L - d - LVM) >= 2 * G * NVMAX) {
+      // ---- the walk (here: two blocks of full windows lie ahead).  Three
+      // blocks of registers rotate through the roles current / previous /
+      // words of the block two ahead.
+      WalkBlock<G> A, B, C;
+      uint32_t da = d; // first element of the newest block that has been through the tables
+      bool match = false;
+      walk_load<S, G, true, 0>(in, da, sig, last_word);
+      walk_load<S, G, true, 1>(in, da + (uint32_t)(G * NVMAX), sig, last_word);
+      walk_load<S, G, true, 2>(in, da + (uint32_t)(2 * G * NVMAX), sig, last_word);
+      agpr_take4<0, 2 * G>(A.word);
+      walk_tables<S, G>(A, T, da, sig, hmask, validc);
+      // CUR takes the block behind the newest one (it has to be made of full
+      // windows), P1 is the newest one, P2 the one before it
+#define HC_WALK_STEP(CUR, P1, P2, RC, YOUNGER, HAVE_P1, HAVE_P2)                            \
+      {                                                                                     \
+        const uint32_t dn = da + (uint32_t)(G * NVMAX);                                     \
+        if ((int)(L - dn - LVM) < G * NVMAX) {                                              \
+          d = walk_drain<S, G, (RC + 2) % 3>(P1, P2, HAVE_P1, T, in, da, sig, validc, match); \
+          break; }                                                                          \
+        const int j = walk_step<S, G, RC, YOUNGER, HAVE_P2>(CUR, P1, P2, T, in, dn, sig,    \
+                                                            hmask, last_word, validc);      \
+        if (j < G) { d = da - (uint32_t)(G * NVMAX) + (uint32_t)(j * NVMAX); match = true; break; } \
+        da = dn;                                                                            \
       }
-      // the three windows in flight rotate through the roles (no copies)
-      Window Qd, Nd; // on kWalkDrain: the two undecided windows
-      int r;
-      for (;;) {
-        r = walk_step<S, NVMAX>(A, B, C, D, table, in, L, last_word, hmask, rev_lane,
-                                rev_addr4_full, perm_addr4, lane);
-        if (r != kWalkOn) {
-          W = A; Qd = B; Nd = C;
-          break;
+      do { // (the first two steps have fewer loads behind them and nothing to decide yet)
+        HC_WALK_STEP(B, A, C, 1, 2 * G, false, false)
+        HC_WALK_STEP(C, B, A, 2, 3 * G, true, true)
+        for (;;) {
+          HC_WALK_STEP(A, C, B, 0, 4 * G, true, true)
+          HC_WALK_STEP(B, A, C, 1, 4 * G, true, true)
+          HC_WALK_STEP(C, B, A, 2, 4 * G, true, true)
         }
-        r = walk_step<S, NVMAX>(B, C, A, D, table, in, L, last_word, hmask, rev_lane,
-                                rev_addr4_full, perm_addr4, lane);
-        if (r != kWalkOn) {
-          W = B; Qd = C; Nd = A;
-          break;
-        }
-        r = walk_step<S, NVMAX>(C, A, B, D, table, in, L, last_word, hmask, rev_lane,
-                                rev_addr4_full, perm_addr4, lane);
-        if (r != kWalkOn) {
-          W = C; Qd = A; Nd = B;
-          break;
-        }
-      }
-      if (r == kWalkDrain) {
-        // the oldest window had no match; the two behind it, oldest first
-        const uint32_t nwQ = (uint32_t)__builtin_amdgcn_ds_bpermute(
-            (int)(window_winner(Qd, lane) * 4u), (int)Qd.word);
-        D = window_decide<NVMAX>(Qd, nwQ, lane);
-        if (D.match) {
-          window_undo(Nd, table);
-          W = Qd;
-        } else {
-          const uint32_t nwN = (uint32_t)__builtin_amdgcn_ds_bpermute(
-              (int)(window_winner(Nd, lane) * 4u), (int)Nd.word);
-          D = window_decide<NVMAX>(Nd, nwN, lane);
-          W = Nd;
-        }
-      }
-      if (D.match) {
-        window_insert_first<NVMAX>(W, table, D.f, perm_addr4, lane);
-        emit_match<S>(out, c, in, token_start, W.d, W.word, D, L, lane, d);
-        next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
-        token_start = d;
-        cold = false;
-        continue;
-      }
-      // (only after a drain: W is the last window, its words-two-behind load
-      // belongs to the window after the next one, so the next one's words
-      // are those its predecessor loaded)
-      d = W.d + (uint32_t)NVMAX;
-      next = Qd.next_word;
-      // (at least one more window follows, not three full ones)
+      } while (false);
+#undef HC_WALK_STEP
+      // the tables are in the state before the window at d, which has a match,
+      // or (!match) the walk has run out of blocks of full windows at d
+      next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+      cold = match ? 0 : 1; // (1: not back into the walk for the few windows left)
     }
 
     if (d + LVM >= L) {
@@ -750,28 +953,26 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
     Window P;
     uint32_t pr;
     window_begin<S, NVMAX>(P, d, next, L, hmask, lane);
-    lds_read_u16_with_bpermute(
-        table + P.hpos, rev_addr4, P.hpos | (P.valid ? 0x80000000u : 0u), P.h_old, pr);
-    window_candidate<S>(P, in, last_word, lane, cold);
-    // (no insert image yet: after a window with a match this one most likely
-    // has one too and would not use it)
-    window_markers<NVMAX, false>(P, table, pr, rev_lane, perm_addr4, lane);
+    lds_lookup_with_bpermute(T, P.hpos, rev_addr4, P.hpos | (P.valid ? 0x80000000u : 0u),
+                             P.h_old, P.t_old, pr);
+    window_candidate<S>(P, T, in, last_word, lane, cold > 0);
+    window_markers(P, T, pr, rev_lane);
     const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
         (int)(window_winner(P, lane) * 4u), (int)P.word);
     const Decision D = window_decide<NVMAX>(P, nw, lane);
     if (D.match) {
-      window_insert_first<NVMAX>(P, table, D.f, perm_addr4, lane);
+      window_insert_first<NVMAX>(P, T, D.f, perm_addr4, sig, hmask, lane);
       emit_match<S>(out, c, in, token_start, P.d, P.word, D, L, lane, d);
       next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
       token_start = d;
-      cold = false;
+      cold = 0;
     } else {
       // no match in this window (reference :958-962): all nv lanes go in
-      window_insert_first<NVMAX>(P, table, P.nv, perm_addr4, lane);
+      window_insert_first<NVMAX>(P, T, P.nv, perm_addr4, sig, hmask, lane);
       d += (uint32_t)P.nv;
-      next = cold ? P.next_word
-                  : load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
-      cold = true;
+      next = cold > 0 ? P.next_word
+                      : load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+      ++cold;
     }
   }
   if (lane == 0)
@@ -1007,9 +1208,9 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
 
 // ---- launchers -----------------------------------------------------------
 
-size_t lz4_compress_lds_bytes(uint32_t ht_size)
+size_t lz4_compress_lds_bytes(uint32_t ht_size, bool tags)
 {
-  return (ht_size * 2 + 15) & ~15u;
+  return (ht_size * (tags ? 3u : 2u) + 15) & ~15u;
 }
 
 namespace {
@@ -1022,17 +1223,20 @@ constexpr int kMaxDevices = 64;
 std::atomic<int> g_num_cus[kMaxDevices];
 std::atomic<int> g_lds_raised[kMaxDevices]; // 0 = not yet, 1 = done, < 0 = -hipError
 
+// -1: no current device, or one beyond the per-device state kept here
 int current_device()
 {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
-    dev = 0;
+    return -1;
   return dev;
 }
 
 int num_cus_of_current_device()
 {
   const int dev = current_device();
+  if (dev < 0)
+    return 256;
   int n = g_num_cus[dev].load(std::memory_order_relaxed);
   if (n == 0) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
@@ -1042,35 +1246,47 @@ int num_cus_of_current_device()
   return n;
 }
 
+typedef void (*CompressKernel)(
+    const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t);
+
+// the kernel for element size `elem_size` (1, 2 or 4 bytes) with or without tag tables
+CompressKernel compress_kernel_for(int elem_size, bool tags)
+{
+  switch (elem_size) {
+  case 1: return tags ? lz4_compress_kernel<1, true> : lz4_compress_kernel<1, false>;
+  case 2: return tags ? lz4_compress_kernel<2, true> : lz4_compress_kernel<2, false>;
+  default: return tags ? lz4_compress_kernel<4, true> : lz4_compress_kernel<4, false>;
+  }
+}
+
 // more than 64 KiB of dynamic LDS has to be asked for, once per kernel and device
 hipError_t raise_dynamic_lds_limit()
 {
   const int dev = current_device();
+  if (dev < 0)
+    return hipErrorInvalidDevice;
   const int state = g_lds_raised[dev].load(std::memory_order_acquire);
   if (state == 1)
     return hipSuccess;
   if (state < 0)
     return (hipError_t)(-state);
-  hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (r == hipSuccess)
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (r == hipSuccess)
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_compress_kernel<4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t r = hipSuccess;
+  for (int es = 1; es <= 4 && r == hipSuccess; es *= 2)
+    for (int tags = 0; tags < 2 && r == hipSuccess; ++tags)
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(compress_kernel_for(es, tags != 0)),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   g_lds_raised[dev].store(r == hipSuccess ? 1 : -(int)r, std::memory_order_release);
   return r;
 }
 
 } // namespace
 
-Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch)
+Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch, bool tags)
 {
   const int num_cus = num_cus_of_current_device();
   constexpr uint32_t kLdsPerCu = 160u * 1024u;
   Lz4CompressShape sh;
-  sh.table_stride = (uint32_t)lz4_compress_lds_bytes(ht_size);
+  sh.table_stride = (uint32_t)lz4_compress_lds_bytes(ht_size, tags);
   uint32_t w = kLdsPerCu / sh.table_stride;
   if (w > (uint32_t)kLz4MaxWavesPerGroup)
     w = kLz4MaxWavesPerGroup;
@@ -1082,7 +1298,7 @@ Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch)
   // exhausted and leave at once
   const size_t per_cu = kLdsPerCu / sh.lds_bytes;
   const size_t want = (batch + w - 1) / w;
-  const size_t cap = (size_t)num_cus * (per_cu > 4 ? 4 : per_cu);
+  const size_t cap = (size_t)num_cus * (per_cu > 8 ? 8 : per_cu);
   sh.groups = (uint32_t)(want < cap ? want : cap);
   return sh;
 }
@@ -1090,9 +1306,9 @@ Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch)
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, uint32_t* ticket, size_t max_chunk_bytes, hipStream_t stream)
+    size_t batch, int elem_size, uint32_t* ticket, size_t max_chunk_bytes, bool tags, hipStream_t stream)
 {
-  const Lz4CompressShape sh = lz4_compress_shape(ht_size, batch);
+  const Lz4CompressShape sh = lz4_compress_shape(ht_size, batch, tags);
   // about 16 KiB of input per ticket, but at least 4 tickets per wave so
   // that the last ones even out the load
   uint32_t per_ticket = 1;
@@ -1110,20 +1326,8 @@ hipError_t lz4_launch_compress(
   const hipError_t raised = raise_dynamic_lds_limit();
   if (raised != hipSuccess)
     return raised;
-  switch (elem_size) {
-  case 1:
-    lz4_compress_kernel<1><<<grid, block, sh.lds_bytes, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket, per_ticket);
-    break;
-  case 2:
-    lz4_compress_kernel<2><<<grid, block, sh.lds_bytes, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket, per_ticket);
-    break;
-  default:
-    lz4_compress_kernel<4><<<grid, block, sh.lds_bytes, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket, per_ticket);
-    break;
-  }
+  compress_kernel_for(elem_size, tags)<<<grid, block, sh.lds_bytes, stream>>>(
+      in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket, per_ticket);
   return hipSuccess;
 }
 

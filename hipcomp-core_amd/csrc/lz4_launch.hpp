@@ -9,11 +9,15 @@
 
 namespace hcamd {
 
-// LDS bytes of one chunk's hash table.
-size_t lz4_compress_lds_bytes(uint32_t ht_size);
+// LDS bytes of one chunk's tables: positions (u16 per slot) and, with `tags`,
+// the tag table (u8 per slot) that spares the encoder most candidate fetches.
+size_t lz4_compress_lds_bytes(uint32_t ht_size, bool tags);
 
-// Most waves (= chunks in flight) one compression workgroup holds.
-constexpr int kLz4MaxWavesPerGroup = 16;
+// Most waves (= chunks in flight) one compression workgroup holds.  Four (one
+// per SIMD): the kernel may then use up to 256 vector registers and keeps
+// clear of the accumulation registers, which its walk uses by name
+// (lz4_kernels.hip, HC_WALK_AGPRS; tests/test_abi_cpu.py checks the build).
+constexpr int kLz4MaxWavesPerGroup = 4;
 
 // Launch shape of the compression kernel: `waves` chunks in flight per
 // workgroup, each with its own `table_stride` bytes of LDS.
@@ -24,7 +28,7 @@ struct Lz4CompressShape
   uint32_t lds_bytes;
   uint32_t groups;
 };
-Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch);
+Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch, bool tags);
 
 // `ticket` is one zero-initialised-by-the-launcher uint32 in device memory
 // (in the caller's temp buffer) from which the waves of the persistent
@@ -33,7 +37,7 @@ Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch);
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, uint32_t* ticket, size_t max_chunk_bytes, hipStream_t stream);
+    size_t batch, int elem_size, uint32_t* ticket, size_t max_chunk_bytes, bool tags, hipStream_t stream);
 
 // write_out == false: parse-only pass that reports sizes.
 void lz4_launch_decompress(

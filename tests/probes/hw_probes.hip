@@ -6,7 +6,9 @@
 //  (1) several lanes of one wave execute ONE global_store_short to the same
 //      address: which lane's value survives?  (the reference's
 //      insertHashTableWarp does this, src/LZ4Kernels.hiph:734-737)
-//  (2) the same for ONE ds_write_b16 (this library keeps the table in LDS).
+//  (2) the same for ONE ds_write_b16 (this library keeps the table in LDS);
+//  (3) the same for ONE ds_write_b8 (the tag table next to it must keep the
+//      tag of the very lane whose position survives in (2)).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
@@ -31,6 +33,27 @@ __global__ void k_lds_store_short(uint16_t* out, const int* slot, unsigned long 
   __syncthreads();
   for (int i = t; i < nslots; i += 64)
     out[i] = tab[i];
+}
+
+__global__ void k_lds_store_byte(uint16_t* out, const int* slot, unsigned long long mask, int nslots)
+{
+  extern __shared__ uint8_t tabb[];
+  const int t = threadIdx.x;
+  for (int i = t; i < nslots; i += 64)
+    tabb[i] = 0xFF;
+  __syncthreads();
+  const int s = slot[t];
+  if ((mask >> t) & 1ull)
+    tabb[s] = (uint8_t)(100 + t);
+  __syncthreads();
+  for (int i = t; i < nslots; i += 64)
+    out[i] = tabb[i] == 0xFF ? (uint16_t)0xFFFF : (uint16_t)(tabb[i] + 900); // same scale as the short probes
+}
+
+extern "C" int probe_lds_store_byte(uint16_t* out, const int* slot, unsigned long long mask, int nslots, hipStream_t st)
+{
+  k_lds_store_byte<<<1, 64, nslots, st>>>(out, slot, mask, nslots);
+  return (int)hipGetLastError();
 }
 
 extern "C" int probe_global_store_short(uint16_t* out, const int* slot, unsigned long long mask, hipStream_t st)

@@ -39,7 +39,10 @@ def _run(lib, space, mask, slots, nslots, cuda):
     out = torch.full((nslots,), 0xFFFF, dtype=torch.int32, device=cuda).to(torch.int16)
     slot = torch.tensor(slots, dtype=torch.int32, device=cuda)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    if space == "global":
+    if space == "lds8":
+        rc = lib.probe_lds_store_byte(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(slot.data_ptr()),
+                                      ctypes.c_ulonglong(mask), nslots, st)
+    elif space == "global":
         rc = lib.probe_global_store_short(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(slot.data_ptr()),
                                           ctypes.c_ulonglong(mask), st)
     else:
@@ -50,12 +53,14 @@ def _run(lib, space, mask, slots, nslots, cuda):
     return [v & 0xFFFF for v in out.cpu().tolist()]
 
 
-@pytest.mark.parametrize("space", ["global", "lds"])
+@pytest.mark.parametrize("space", ["global", "lds", "lds8"])
 def test_same_address_store_winner(cuda, oracle, space):
     """global_store_short: survivor = last lane in the measured write order
     (oracle.gfx950_store_order_key) -- what the reference's hash-table insert
     gets from the hardware.  ds_write_b16: survivor = highest lane -- what this
-    library's insert_window() relies on."""
+    library's table insert (lz4_kernels.hip: sigma order) relies on.  ds_write_b8:
+    the same lane -- the tag table is written next to the position table by the
+    same lanes and has to keep the tag of the lane whose position survives."""
     lib = _lib()
     nslots = 16384
     groups = bad = 0

@@ -480,38 +480,54 @@ __device__ __forceinline__ uint32_t match_length(
 // on the window's words only -- so the 5 G LDS operations of a block are
 // issued back to back (LDS operations of a wave execute in order) and cost
 // their issue slots, not their latency.  What the lookups return is looked at
-// one block later:
+// in later steps (walk_step):
 //   * a lane whose read-back is not its own position shares its slot with
 //     another lane of the window: the only lanes that can be one half of an
 //     in-window duplicate (equal words hash alike and only one lane per slot
 //     reads itself back).  Nearly always there is none; else exact compare.
 //   * a lane whose slot held an entry with its word's tag: its candidate is
 //     fetched (about one lane in four windows on random data, instead of a
-//     64-line gather per window) and compared one block later.
+//     64-line gather per window) and compared.
 // A window that does have a match ends the walk: the inserts of all younger
 // windows and its own are taken back (newest first, from the kept old slot
 // contents) and the one-window path redoes it.
+//
+// A lone wave on its SIMD pays ~4 cycles per instruction and ~30 for every
+// trip of a value from the vector to the scalar unit and back (a ballot
+// combined by s_and and consumed by v_cndmask, an exec mask made from a
+// compare: scripts/probes/latency_table.hip), and the walk has no second wave
+// to hide that behind.  So its per-lane decisions stay per lane (v_cmp into
+// vcc, v_cndmask out of it; a lane that must not store writes to a scratch
+// slot behind the tables instead of being masked off) and are gathered into
+// ONE scalar test per block (walk_decide).  Lane constants do the rest: the
+// lanes behind the last valid window lane (3 for bytes, 1 for shorts) walk as
+// copies of window lane 31 -- the one lane that never stores -- and window
+// lane 63 of a 64-lane window compares with a slot number no lane can have.
 // ---------------------------------------------------------------------------
 template <int G>
 struct WalkBlock
 {
-  uint32_t word[G];      // sigma order
+  uint32_t word[G];   // sigma order
   uint32_t hpos[G];
-  uint16_t h_old[G];     // (kept as narrow as the tables hold them: a widening here makes the
-  uint8_t t_old[G];      //  compiler wait for the lookup in the step that issued it)
-  uint16_t rb[G];        // my slot after the window's insert
-  uint64_t tprobe[G];    // lanes whose candidate was fetched (uniform)
-  uint64_t l31_sharers;  // valid lanes that share window lane 31's slot, all windows of the block together (uniform)
+  uint32_t tag[G];
+  uint32_t pos[G];    // my element
+  uint16_t h_old[G];  // (kept as narrow as the tables hold them: a widening here makes the
+  uint8_t t_old[G];   //  compiler wait for the lookup in the step that issued it)
+  uint16_t rb[G];     // my slot after the window's insert
+  uint32_t at[G];     // element whose 4 bytes were fetched as my candidate's; pos = none
+  uint32_t sharer;    // != 0: I share window lane 31's slot in some window of the block
 };
 
-// A 16- or 8-bit table entry as a full register: hides from the compiler that
-// the upper bits are zero (knowing it, it narrows some users to 16-bit
-// compares, reads the entry "any-extended" and then masks it for the others).
-__device__ __forceinline__ uint32_t as_full_register(uint32_t v)
+// per-lane constants of the walk
+struct WalkLanes
 {
-  asm("" : "+v"(v));
-  return v;
-}
+  uint32_t sig;        // my window lane (sigma order; lanes behind the last valid one: 31)
+  uint32_t never;      // OR-ed into my slot number for the "shares lane 31's slot" test: window
+                       // lane 63 of a 64-lane window stores whatever that test says
+  uint32_t counts;     // ~0: my read-back / sharer flag counts (valid lane other than window lane 31)
+  uint32_t scratch_pos, scratch_tag; // LDS addresses a lane that does not store writes to
+  uint64_t validc;     // the valid lanes as a mask (slow paths)
+};
 
 // The walk's loads are issued and awaited by hand, and they land in
 // ACCUMULATION registers (AGPRs), which the compiler does not allocate:
@@ -537,9 +553,14 @@ __device__ __forceinline__ void agpr_load_u32(cgptr base, uint32_t byte_off)
 }
 
 // waits until at most N younger loads are in flight, then a[A0 .. A0+3] -> r
-template <int A0, int N>
+template <int A0, int N_>
 __device__ __forceinline__ void agpr_take4(uint32_t (&r)[4])
 {
+#ifdef HC_ABL_NOWAIT // measurement builds only (wrong output): 1 = no wait for candidate words, 2 = none for window words, 3 = neither
+  constexpr int N = ((HC_ABL_NOWAIT & 1) && A0 >= 12) || ((HC_ABL_NOWAIT & 2) && A0 < 12) ? 63 : N_;
+#else
+  constexpr int N = N_;
+#endif
   asm volatile("s_waitcnt vmcnt(%4)\n\t"
                "v_accvgpr_read_b32 %0, a[%5]\n\t"
                "v_accvgpr_read_b32 %1, a[%6]\n\t"
@@ -573,87 +594,184 @@ __device__ __forceinline__ void walk_load(cgptr in, uint32_t d0, uint32_t sig, u
 // table traffic of a block: lookup, insert, read-back per window, no waits
 template <int S, int G, class TT>
 __device__ __forceinline__ void walk_tables(
-    WalkBlock<G>& B, const TT& T, uint32_t d0, uint32_t sig, uint32_t hmask, uint64_t validc)
+    WalkBlock<G>& B, const TT& T, uint32_t d0, const WalkLanes& W, uint32_t hmask)
 {
   constexpr int NVMAX = kWave - 3 / S;
-  uint64_t sharers = 0;
+  B.sharer = 0;
 #pragma unroll
   for (int k = 0; k < G; ++k) {
     const uint32_t hs = hash_sum(B.word[k]);
     const uint32_t hp = hs & hmask;
     B.hpos[k] = hp;
-    uint64_t in31;
-    const uint64_t store = sigma_store_mask(hp, validc, NVMAX == 64, in31);
-    sharers |= in31;
+    B.tag[k] = tag_of(hs);
+    B.pos[k] = d0 + (uint32_t)(k * NVMAX) + W.sig;
+    const uint32_t pa = T.pos_lds + 2u * hp, ta = T.tag_lds + hp;
     B.h_old[k] = T.pos[hp];
-    if (T.tags)
+    if (TT::tags)
       B.t_old[k] = T.tag[hp];
     lds_lane_exchange_fence();
-    tables_store_masked(T, hp, (d0 + (uint32_t)(k * NVMAX) + sig) & 0xFFFFu, tag_of(hs), store);
+    // the insert rule (insert_sigma) per lane: a lane in window lane 31's slot
+    // stores to the scratch slot instead and notes that it shares (window
+    // lane 63 of a 64-lane window stores in any case but is a sharer like any
+    // other).  ds_write_b16 takes the low half of the position.
+    const uint32_t h31 = read_lane(hp, 63);
+    uint32_t pa_st, ta_st;
+    uint32_t mine = hp;
+    if (NVMAX == 64) {
+      mine = hp | W.never;
+      asm volatile("v_cmp_ne_u32_e32 vcc, %1, %2\n\t"
+                   "v_cndmask_b32_e32 %0, 1, %0, vcc"
+                   : "+v"(B.sharer) : "s"(h31), "v"(hp) : "vcc");
+    }
+    uint32_t unused = 0;
+    uint32_t& sharer = NVMAX == 64 ? unused : B.sharer;
+    if (TT::tags)
+      asm volatile("v_cmp_ne_u32_e32 vcc, %3, %4\n\t"
+                   "v_cndmask_b32_e32 %0, %5, %6, vcc\n\t"
+                   "v_cndmask_b32_e32 %1, %7, %8, vcc\n\t"
+                   "v_cndmask_b32_e32 %2, 1, %2, vcc\n\t"
+                   "ds_write_b16 %0, %9\n\t"
+                   "ds_write_b8 %1, %10"
+                   : "=&v"(pa_st), "=&v"(ta_st), "+v"(sharer)
+                   : "s"(h31), "v"(mine), "v"(W.scratch_pos), "v"(pa), "v"(W.scratch_tag), "v"(ta),
+                     "v"(B.pos[k]), "v"(B.tag[k])
+                   : "vcc", "memory");
+    else
+      asm volatile("v_cmp_ne_u32_e32 vcc, %2, %3\n\t"
+                   "v_cndmask_b32_e32 %0, %4, %5, vcc\n\t"
+                   "v_cndmask_b32_e32 %1, 1, %1, vcc\n\t"
+                   "ds_write_b16 %0, %6"
+                   : "=&v"(pa_st), "+v"(sharer)
+                   : "s"(h31), "v"(mine), "v"(W.scratch_pos), "v"(pa), "v"(B.pos[k])
+                   : "vcc", "memory");
+    (void)ta_st;
     B.rb[k] = T.pos[hp];
     lds_lane_exchange_fence();
   }
-  B.l31_sharers = sharers & validc & ~kSigmaLane31;
 }
 
 // What the lookups of a block returned: the candidates that cannot be ruled
 // out are fetched.  ONE load per window whatever the data (lanes without a
 // candidate re-read their own window word, a line that is in L1), so that the
-// loads in flight can be counted.
-template <int S, int G, int R, class TT>
-__device__ __forceinline__ void walk_probe(
-    WalkBlock<G>& B, const TT& T, cgptr in, uint32_t d0, uint32_t sig, uint64_t validc)
+// loads in flight can be counted.  The table entries go into the asm as the
+// LDS reads left them (ds_read_u16 / ds_read_u8 fill the register with
+// zeroes); the statements are volatile so that the compiler cannot move them --
+// and with them the wait for the lookups -- up into the step that issued those.
+// SMALL: the chunk has at most 65536 BYTES, so a slot's position is the
+// candidate itself and its distance always fits.
+template <int S, int G, int R, bool SMALL, class TT>
+__device__ __forceinline__ void walk_probe(WalkBlock<G>& B, const TT& T, cgptr in)
 {
-  constexpr int NVMAX = kWave - 3 / S;
-  const uint64_t unfiltered = T.filter ? 0ull : ~0ull;
-  uint32_t at[G]; // tprobe ? candidate : own position
+  const uint32_t tag_bits = T.filter ? 0xFFu : 0u; // no filter: every tag "equal"
 #pragma unroll
   for (int k = 0; k < G; ++k) {
-    const uint32_t pos = d0 + (uint32_t)(k * NVMAX) + sig;
-    const uint32_t h_old = as_full_register(B.h_old[k]);
-    const uint32_t back = (pos - 1u - h_old) & 0xFFFFu;
-    uint64_t tp = wave_ballot(h_old != kNullOffset) & wave_ballot(back < 65535u / S) & validc; // see window_candidate
-    if (TT::tags)
-      tp &= wave_ballot(as_full_register(B.t_old[k]) == tag_of(hash_sum(B.word[k]))) | unfiltered;
-    B.tprobe[k] = tp;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(at[k]) : "v"(pos), "v"(pos - 1u - back), "s"(tp));
+    uint32_t at;
+    if (SMALL) {
+      if (TT::tags)
+        asm volatile("v_xor_b32_e32 %0, %3, %4\n\t"
+                     "v_and_b32_e32 %0, %5, %0\n\t"
+                     "v_cmp_eq_u32_e32 vcc, 0, %0\n\t"
+                     "v_cndmask_b32_e32 %0, %1, %2, vcc\n\t"
+                     "v_cmp_ne_u32_e32 vcc, 0xffff, %2\n\t"
+                     "v_cndmask_b32_e32 %0, %1, %0, vcc"
+                     : "=&v"(at)
+                     : "v"(B.pos[k]), "v"((uint32_t)B.h_old[k]), "v"((uint32_t)B.t_old[k]), "v"(B.tag[k]), "s"(tag_bits)
+                     : "vcc");
+      else
+        asm volatile("v_cmp_ne_u32_e32 vcc, 0xffff, %2\n\t"
+                     "v_cndmask_b32_e32 %0, %1, %2, vcc"
+                     : "=&v"(at)
+                     : "v"(B.pos[k]), "v"((uint32_t)B.h_old[k])
+                     : "vcc");
+    } else {
+      // candidate = nearest element before mine with the slot's low 16 bits,
+      // usable if its byte distance fits 16 bits (see window_candidate)
+      uint32_t back;
+      asm volatile("v_sub_u32_e32 %1, %2, %3\n\t"
+                   "v_add_u32_e32 %1, -1, %1\n\t"
+                   "v_and_b32_e32 %1, 0xffff, %1\n\t"
+                   "v_sub_u32_e32 %0, %2, %1\n\t"
+                   "v_add_u32_e32 %0, -1, %0\n\t"
+                   "v_cmp_gt_u32_e32 vcc, %4, %1\n\t"
+                   "v_cndmask_b32_e32 %0, %2, %0, vcc\n\t"
+                   "v_cmp_ne_u32_e32 vcc, 0xffff, %3\n\t"
+                   "v_cndmask_b32_e32 %0, %2, %0, vcc"
+                   : "=&v"(at), "=&v"(back)
+                   : "v"(B.pos[k]), "v"((uint32_t)B.h_old[k]), "s"(65535u / S)
+                   : "vcc");
+      if (TT::tags) {
+        uint32_t tdiff;
+        asm volatile("v_xor_b32_e32 %1, %3, %4\n\t"
+                     "v_and_b32_e32 %1, %5, %1\n\t"
+                     "v_cmp_eq_u32_e32 vcc, 0, %1\n\t"
+                     "v_cndmask_b32_e32 %0, %2, %0, vcc"
+                     : "+v"(at), "=&v"(tdiff)
+                     : "v"(B.pos[k]), "v"((uint32_t)B.t_old[k]), "v"(B.tag[k]), "s"(tag_bits)
+                     : "vcc");
+      }
+    }
+    B.at[k] = at;
   }
-  agpr_load_u32<12 + 4 * R + 0>(in, at[0] * (uint32_t)S);
-  agpr_load_u32<12 + 4 * R + 1>(in, at[1] * (uint32_t)S);
-  agpr_load_u32<12 + 4 * R + 2>(in, at[2] * (uint32_t)S);
-  agpr_load_u32<12 + 4 * R + 3>(in, at[3] * (uint32_t)S);
+  agpr_load_u32<12 + 4 * R + 0>(in, B.at[0] * (uint32_t)S);
+  agpr_load_u32<12 + 4 * R + 1>(in, B.at[1] * (uint32_t)S);
+  agpr_load_u32<12 + 4 * R + 2>(in, B.at[2] * (uint32_t)S);
+  agpr_load_u32<12 + 4 * R + 3>(in, B.at[3] * (uint32_t)S);
 }
 
 // first window of the block that has a match, G if none
 template <int S, int G>
 __device__ __forceinline__ int walk_decide(
-    const WalkBlock<G>& B, const uint32_t (&cand_word)[G], uint32_t d0, uint32_t sig, uint64_t validc)
+    const WalkBlock<G>& B, const uint32_t (&cand_word)[G], const WalkLanes& W)
 {
-  constexpr int NVMAX = kWave - 3 / S;
-  uint64_t tm[G], fl[G];
-  uint64_t any = 0;
+  static_assert(G == 4, "operand lists below");
+  // per lane: miss = 0 iff one of my candidates holds my word (a lane without
+  // a candidate has read its own bytes: 1); odd != 0 iff one of my read-backs
+  // is not my position or I share window lane 31's slot
+  uint32_t miss, odd, t0, t1;
+  asm volatile("v_xor_b32_e32 %0, %4, %5\n\t"
+               "v_cmp_ne_u32_e32 vcc, %6, %7\n\t"
+               "v_cndmask_b32_e32 %0, 1, %0, vcc\n\t"
+               "v_xor_b32_e32 %2, %8, %9\n\t"
+               "v_cmp_ne_u32_e32 vcc, %10, %11\n\t"
+               "v_cndmask_b32_e32 %2, 1, %2, vcc\n\t"
+               "v_xor_b32_e32 %3, %12, %13\n\t"
+               "v_cmp_ne_u32_e32 vcc, %14, %15\n\t"
+               "v_cndmask_b32_e32 %3, 1, %3, vcc\n\t"
+               "v_min3_u32 %0, %0, %2, %3\n\t"
+               "v_xor_b32_e32 %2, %16, %17\n\t"
+               "v_cmp_ne_u32_e32 vcc, %18, %19\n\t"
+               "v_cndmask_b32_e32 %2, 1, %2, vcc\n\t"
+               "v_min_u32_e32 %0, %0, %2\n\t"
+               "v_xor_b32_e32 %1, %20, %7\n\t"
+               "v_xor_b32_e32 %2, %21, %11\n\t"
+               "v_xor_b32_e32 %3, %22, %15\n\t"
+               "v_or3_b32 %1, %1, %2, %3\n\t"
+               "v_xor_b32_e32 %2, %23, %19\n\t"
+               "v_or_b32_e32 %1, %1, %2\n\t"
+               "v_and_b32_e32 %1, 0xffff, %1"
+               : "=&v"(miss), "=&v"(odd), "=&v"(t0), "=&v"(t1)
+               : "v"(cand_word[0]), "v"(B.word[0]), "v"(B.at[0]), "v"(B.pos[0]),
+                 "v"(cand_word[1]), "v"(B.word[1]), "v"(B.at[1]), "v"(B.pos[1]),
+                 "v"(cand_word[2]), "v"(B.word[2]), "v"(B.at[2]), "v"(B.pos[2]),
+                 "v"(cand_word[3]), "v"(B.word[3]), "v"(B.at[3]), "v"(B.pos[3]),
+                 "v"((uint32_t)B.rb[0]), "v"((uint32_t)B.rb[1]), "v"((uint32_t)B.rb[2]), "v"((uint32_t)B.rb[3])
+               : "vcc");
+  odd = (odd | B.sharer) & W.counts;
+  // the one trip to the scalar unit of the block
+  const uint64_t suspects = wave_ballot(miss == 0) | wave_ballot(odd != 0);
+  if (__builtin_expect(suspects == 0, 1))
+    return G;
+  const uint64_t validc = W.validc;
 #pragma unroll
   for (int k = 0; k < G; ++k) {
-    const uint32_t pos16 = (d0 + (uint32_t)(k * NVMAX) + sig) & 0xFFFFu;
-    tm[k] = wave_ballot(cand_word[k] == B.word[k]) & B.tprobe[k];
+    if (wave_ballot(cand_word[k] == B.word[k] && B.at[k] != B.pos[k]) & validc)
+      return k;
     // a lane that does not read back its own insert shares its slot; window
     // lane 31 never stores (for it the test says nothing), it takes part iff
     // another lane is in its slot
-    fl[k] = wave_ballot(as_full_register(B.rb[k]) != pos16) & validc & ~kSigmaLane31;
-    any |= tm[k] | fl[k];
-  }
-  if (__builtin_expect((any | B.l31_sharers) == 0, 1))
-    return G;
-#pragma unroll
-  for (int k = 0; k < G; ++k) {
-    if (tm[k])
-      return k;
-    uint64_t U = fl[k];
-    if (B.l31_sharers) { // (rare) is it this window in which window lane 31 has company?
-      const uint64_t in31 = wave_ballot(B.hpos[k] == read_lane(B.hpos[k], 63)) & validc & ~kSigmaLane31;
-      if (in31)
-        U |= kSigmaLane31;
-    }
+    uint64_t U = wave_ballot((uint32_t)B.rb[k] != (B.pos[k] & 0xFFFFu)) & validc & ~kSigmaLane31;
+    if (wave_ballot(B.hpos[k] == read_lane(B.hpos[k], 63)) & validc & ~kSigmaLane31)
+      U |= kSigmaLane31;
     while (U) { // exact: does a slot sharer hold the word of another lane?
       const int u = __builtin_ctzll(U);
       U &= U - 1;
@@ -692,27 +810,27 @@ __device__ __forceinline__ void walk_undo(const WalkBlock<G>& B, const TT& T, in
 // the first two steps of a walk) and behind the candidate words of p2 2 G.
 // Returns the window of p2 that has a match (the tables are then back in the
 // state before that window), G if none (or no p2 yet).
-template <int S, int G, int RC, int WORDS_YOUNGER, bool HAVE_P2, class TT>
+template <int S, int G, int RC, int WORDS_YOUNGER, bool HAVE_P2, bool SMALL, class TT>
 __device__ __forceinline__ int walk_step(
-    WalkBlock<G>& cur, WalkBlock<G>& p1, WalkBlock<G>& p2, const TT& T, cgptr in, uint32_t d_cur, uint32_t sig,
-    uint32_t hmask, uint32_t last_word, uint64_t validc)
+    WalkBlock<G>& cur, WalkBlock<G>& p1, WalkBlock<G>& p2, const TT& T, cgptr in, uint32_t d_cur,
+    const WalkLanes& W, uint32_t hmask, uint32_t last_word)
 {
   constexpr int NVMAX = kWave - 3 / S;
   constexpr int R1 = (RC + 2) % 3; // slot of p1, and of the block two ahead of cur
   constexpr int R2 = (RC + 1) % 3; // slot of p2
-  walk_load<S, G, true, R1>(in, d_cur + (uint32_t)(2 * G * NVMAX), sig, last_word);
+  walk_load<S, G, true, R1>(in, d_cur + (uint32_t)(2 * G * NVMAX), W.sig, last_word);
   agpr_take4<4 * RC, WORDS_YOUNGER>(cur.word);
-  walk_tables<S, G>(cur, T, d_cur, sig, hmask, validc);
-  walk_probe<S, G, R1>(p1, T, in, d_cur - (uint32_t)(G * NVMAX), sig, validc);
+  walk_tables<S, G>(cur, T, d_cur, W, hmask);
+  walk_probe<S, G, R1, SMALL>(p1, T, in);
   if (!HAVE_P2)
     return G;
   uint32_t cand_word[G];
   agpr_take4<12 + 4 * R2, 2 * G>(cand_word);
-  const int j = walk_decide<S, G>(p2, cand_word, d_cur - (uint32_t)(2 * G * NVMAX), sig, validc);
+  const int j = walk_decide<S, G>(p2, cand_word, W);
   if (__builtin_expect(j < G, 0)) {
-    walk_undo<G>(cur, T, 0, validc);
-    walk_undo<G>(p1, T, 0, validc);
-    walk_undo<G>(p2, T, j, validc);
+    walk_undo<G>(cur, T, 0, W.validc);
+    walk_undo<G>(p1, T, 0, W.validc);
+    walk_undo<G>(p2, T, j, W.validc);
   }
   return j;
 }
@@ -721,31 +839,76 @@ __device__ __forceinline__ int walk_step(
 // the block before it, if any -- has had its candidates asked for.  Decides
 // both, oldest first.  Returns the element of the first window with a match
 // (the tables are back in the state before it), or the element behind x.
-template <int S, int G, int RX, class TT>
+template <int S, int G, int RX, bool SMALL, class TT>
 __device__ __forceinline__ uint32_t walk_drain(
-    WalkBlock<G>& x, WalkBlock<G>& y, bool have_y, const TT& T, cgptr in, uint32_t dx, uint32_t sig,
-    uint64_t validc, bool& match)
+    WalkBlock<G>& x, WalkBlock<G>& y, bool have_y, const TT& T, cgptr in, uint32_t dx,
+    const WalkLanes& W, bool& match)
 {
   constexpr int NVMAX = kWave - 3 / S;
   constexpr int RY = (RX + 2) % 3;
-  walk_probe<S, G, RX>(x, T, in, dx, sig, validc);
+  walk_probe<S, G, RX, SMALL>(x, T, in);
   uint32_t cw[G];
   if (have_y) {
     agpr_take4<12 + 4 * RY, 0>(cw);
-    const int j = walk_decide<S, G>(y, cw, dx - (uint32_t)(G * NVMAX), sig, validc);
+    const int j = walk_decide<S, G>(y, cw, W);
     if (j < G) {
-      walk_undo<G>(x, T, 0, validc);
-      walk_undo<G>(y, T, j, validc);
+      walk_undo<G>(x, T, 0, W.validc);
+      walk_undo<G>(y, T, j, W.validc);
       match = true;
       return dx - (uint32_t)(G * NVMAX) + (uint32_t)(j * NVMAX);
     }
   }
   agpr_take4<12 + 4 * RX, 0>(cw);
-  const int j = walk_decide<S, G>(x, cw, dx, sig, validc);
+  const int j = walk_decide<S, G>(x, cw, W);
   if (j < G)
-    walk_undo<G>(x, T, j, validc);
+    walk_undo<G>(x, T, j, W.validc);
   match = j < G;
   return dx + (uint32_t)(j * NVMAX);
+}
+
+// The walk from element d on (two blocks of full windows lie ahead).  Three
+// blocks of registers rotate through the stages of walk_step.  Returns the
+// element where it ended: the window there has a match (`match`; the tables are
+// in the state before it) or too few full windows are left for another block.
+template <int S, int G, bool SMALL, class TT>
+__device__ __forceinline__ uint32_t walk_run(
+    const TT& T, cgptr in, uint32_t d, uint32_t L, const WalkLanes& WL, uint32_t hmask, uint32_t last_word,
+    bool& match)
+{
+  constexpr uint32_t LVM = (12 + S - 1) / S;
+  constexpr int NVMAX = kWave - 3 / S;
+  WalkBlock<G> A, B, C;
+  uint32_t da = d; // first element of the newest block that has been through the tables
+  match = false;
+  walk_load<S, G, true, 0>(in, da, WL.sig, last_word);
+  walk_load<S, G, true, 1>(in, da + (uint32_t)(G * NVMAX), WL.sig, last_word);
+  walk_load<S, G, true, 2>(in, da + (uint32_t)(2 * G * NVMAX), WL.sig, last_word);
+  agpr_take4<0, 2 * G>(A.word);
+  walk_tables<S, G>(A, T, da, WL, hmask);
+  // CUR takes the block behind the newest one (it has to be made of full
+  // windows), P1 is the newest one, P2 the one before it
+#define HC_WALK_STEP(CUR, P1, P2, RC, YOUNGER, HAVE_P1, HAVE_P2)                            \
+  {                                                                                         \
+    const uint32_t dn = da + (uint32_t)(G * NVMAX);                                         \
+    if ((int)(L - dn - LVM) < G * NVMAX)                                                    \
+      return walk_drain<S, G, (RC + 2) % 3, SMALL>(P1, P2, HAVE_P1, T, in, da, WL, match);  \
+    const int j = walk_step<S, G, RC, YOUNGER, HAVE_P2, SMALL>(CUR, P1, P2, T, in, dn, WL,  \
+                                                               hmask, last_word);           \
+    if (j < G) {                                                                            \
+      match = true;                                                                         \
+      return da - (uint32_t)(G * NVMAX) + (uint32_t)(j * NVMAX);                            \
+    }                                                                                       \
+    da = dn;                                                                                \
+  }
+  // (the first two steps have fewer loads behind them and nothing to decide yet)
+  HC_WALK_STEP(B, A, C, 1, 2 * G, false, false)
+  HC_WALK_STEP(C, B, A, 2, 3 * G, true, true)
+  for (;;) {
+    HC_WALK_STEP(A, C, B, 0, 4 * G, true, true)
+    HC_WALK_STEP(B, A, C, 1, 4 * G, true, true)
+    HC_WALK_STEP(C, B, A, 2, 4 * G, true, true)
+  }
+#undef HC_WALK_STEP
 }
 
 // The sequence that ends with the match D found in the window at element wd
@@ -855,7 +1018,16 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   T.filter = false;
   const uint32_t sig = sigma_of_lane(lane);
   const int perm_addr4 = (int)(sig * 4u);
-  const uint64_t validc = wave_ballot(sig < (uint32_t)NVMAX); // valid lanes of a full window, sigma order
+  WalkLanes WL;
+  WL.validc = wave_ballot(sig < (uint32_t)NVMAX); // valid lanes of a full window, sigma order
+  WL.sig = sig < (uint32_t)NVMAX ? sig : 31u;
+  WL.never = (NVMAX == 64 && sig == 63u) ? 0x10000u : 0u;
+  WL.counts = (sig < (uint32_t)NVMAX && sig != 31u) ? ~0u : 0u;
+  // behind the tables (lz4_compress_lds_bytes); as vector registers the
+  // compiler cannot re-make from the scalar at every use
+  asm volatile("v_mov_b32_e32 %0, %2\n\tv_add_u32_e32 %1, 2, %0"
+               : "=&v"(WL.scratch_pos), "=v"(WL.scratch_tag)
+               : "s"((T.pos_lds + ht_size * (TAGS ? 3u : 2u) + 1u) & ~1u));
   const uint32_t rev_lane = 63u - (uint32_t)lane;
   const int rev_addr4 = (int)(rev_lane * 4u);
 
@@ -903,40 +1075,10 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   uint32_t token_start = 0; // first element not yet written out
   while (d < L) {
     if (cold >= kLz4WalkAfter && (int)(L - d - LVM) >= 2 * G * NVMAX) {
-      // ---- the walk (here: two blocks of full windows lie ahead).  Three
-      // blocks of registers rotate through the roles current / previous /
-      // words of the block two ahead.
-      WalkBlock<G> A, B, C;
-      uint32_t da = d; // first element of the newest block that has been through the tables
-      bool match = false;
-      walk_load<S, G, true, 0>(in, da, sig, last_word);
-      walk_load<S, G, true, 1>(in, da + (uint32_t)(G * NVMAX), sig, last_word);
-      walk_load<S, G, true, 2>(in, da + (uint32_t)(2 * G * NVMAX), sig, last_word);
-      agpr_take4<0, 2 * G>(A.word);
-      walk_tables<S, G>(A, T, da, sig, hmask, validc);
-      // CUR takes the block behind the newest one (it has to be made of full
-      // windows), P1 is the newest one, P2 the one before it
-#define HC_WALK_STEP(CUR, P1, P2, RC, YOUNGER, HAVE_P1, HAVE_P2)                            \
-      {                                                                                     \
-        const uint32_t dn = da + (uint32_t)(G * NVMAX);                                     \
-        if ((int)(L - dn - LVM) < G * NVMAX) {                                              \
-          d = walk_drain<S, G, (RC + 2) % 3>(P1, P2, HAVE_P1, T, in, da, sig, validc, match); \
-          break; }                                                                          \
-        const int j = walk_step<S, G, RC, YOUNGER, HAVE_P2>(CUR, P1, P2, T, in, dn, sig,    \
-                                                            hmask, last_word, validc);      \
-        if (j < G) { d = da - (uint32_t)(G * NVMAX) + (uint32_t)(j * NVMAX); match = true; break; } \
-        da = dn;                                                                            \
-      }
-      do { // (the first two steps have fewer loads behind them and nothing to decide yet)
-        HC_WALK_STEP(B, A, C, 1, 2 * G, false, false)
-        HC_WALK_STEP(C, B, A, 2, 3 * G, true, true)
-        for (;;) {
-          HC_WALK_STEP(A, C, B, 0, 4 * G, true, true)
-          HC_WALK_STEP(B, A, C, 1, 4 * G, true, true)
-          HC_WALK_STEP(C, B, A, 2, 4 * G, true, true)
-        }
-      } while (false);
-#undef HC_WALK_STEP
+      // ---- the walk (here: two blocks of full windows lie ahead)
+      bool match;
+      d = (len <= 65536u) ? walk_run<S, G, true>(T, in, d, L, WL, hmask, last_word, match)
+                          : walk_run<S, G, false>(T, in, d, L, WL, hmask, last_word, match);
       // the tables are in the state before the window at d, which has a match,
       // or (!match) the walk has run out of blocks of full windows at d
       next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
@@ -1210,7 +1352,8 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
 
 size_t lz4_compress_lds_bytes(uint32_t ht_size, bool tags)
 {
-  return (ht_size * (tags ? 3u : 2u) + 15) & ~15u;
+  // position table, tag table, 4 bytes of scratch (WalkLanes::scratch_*)
+  return (ht_size * (tags ? 3u : 2u) + 4u + 15) & ~15u;
 }
 
 namespace {

@@ -6,7 +6,7 @@ import torch, bench
 hc = importlib.import_module("hipcomp-core_amd")
 lib = hc.default_library()
 dev = torch.device("cuda:0")
-data = bench.gen_data(sys.argv[1] if len(sys.argv) > 1 else "uniform", 8000, dev, 0x5EED0002)
+data = bench.gen_data(sys.argv[1] if len(sys.argv) > 1 else "uniform", 0, 8000, dev, 0x5EED0002)
 codec = hc.batch.Codec("LZ4", hc.LZ4Opts(hc.hipcompType.CHAR), lib=lib)
 for chunk in (65536, 32768, 16384, 8192, 4096, 2048, 1024):
     src = hc.batch.from_device_buffer(data, chunk)

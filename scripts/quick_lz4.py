@@ -13,6 +13,8 @@ ap.add_argument("--dist", default="uniform")
 ap.add_argument("--dtype", default="char")
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--lib", default=None, help="another build of the library (measurement variants)")
+ap.add_argument("--no-verify", action="store_true")
 a = ap.parse_args()
 hc = importlib.import_module("hipcomp-core_amd")
 dev = torch.device("cuda:0")
@@ -23,8 +25,11 @@ for dist in a.dist.split(","):
         else:
             data = bench.gen_data(dist, 0, a.chunks, dev, {"uniform": 0x5EED0002, "harness": 0x5EED0003, "runs": 0x5EED0004}[dist])
         t = hc.hipcompType.CHAR if dt == "char" else hc.hipcompType.INT
-        job = bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(t), data)
-        job.compress(); job.decompress(); torch.cuda.synchronize(); job.verify()
+        lib = hc.HipcompLibrary(os.path.join(ROOT, a.lib)) if a.lib else hc.default_library()
+        job = bench.CodecJob(hc, lib, "LZ4", hc.LZ4Opts(t), data)
+        job.compress(); job.decompress(); torch.cuda.synchronize()
+        if not a.no_verify:
+            job.verify()
         tc, td = bench.time_phases(job, a.reps)
         nb, cb = job.total, job.compressed_bytes()
         line = f"{dist:8s} {dt:4s} n={job.n}: compress {min(tc):8.3f} ms {nb/min(tc)/1e6:8.1f} GB/s | decompress {min(td):8.3f} ms {nb/min(td)/1e6:8.1f} GB/s | ratio {nb/cb:.3f}"

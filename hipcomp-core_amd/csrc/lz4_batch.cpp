@@ -111,14 +111,14 @@ hipcompStatus_t hipcompBatchedLZ4CompressAsync(
   if (batch_size > 0x7FFFFFFFull) // the ticket counter runs past batch_size by up to waves x 64
     return fail(fn, "batch_size must be below 2^31");
   HCAMD_DEVICE_POINTER(fn, device_temp_ptr);
-  // the chunk ticket counter: the first 4-byte aligned word of the temp
-  // buffer -- if the (contract-sized) buffer is too small to hold one, the
-  // kernel runs without it
+  // the chunk ticket counter and the two counters of the sampling kernel: the
+  // first three 4-byte aligned words of the temp buffer -- if the (contract-
+  // sized) buffer is too small to hold them, the kernel runs without
   uint32_t* ticket = nullptr;
   {
     const uintptr_t base = reinterpret_cast<uintptr_t>(device_temp_ptr);
     const uintptr_t aligned = (base + 3u) & ~uintptr_t(3);
-    if (aligned + sizeof(uint32_t) <= base + temp_bytes)
+    if (aligned + 3 * sizeof(uint32_t) <= base + temp_bytes)
       ticket = reinterpret_cast<uint32_t*>(aligned);
   }
 
@@ -126,7 +126,8 @@ hipcompStatus_t hipcompBatchedLZ4CompressAsync(
       reinterpret_cast<const uint8_t* const*>(device_uncompressed_ptrs),
       device_uncompressed_bytes,
       reinterpret_cast<uint8_t* const*>(device_compressed_ptrs),
-      device_compressed_bytes, (uint32_t)ht, batch_size, s, ticket, max_uncompressed_chunk_bytes, /*tags=*/true, stream);
+      device_compressed_bytes, (uint32_t)ht, batch_size, s, ticket, max_uncompressed_chunk_bytes,
+      lz4_mode_from_environment(), stream);
   if (e != hipSuccess)
     return fail(fn, std::string("lz4 compress launch: ") + hipGetErrorString(e));
   std::string why;

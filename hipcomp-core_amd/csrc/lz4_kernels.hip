@@ -42,6 +42,8 @@
 #include "wave_utils.hpp"
 
 #include <atomic>
+#include <cstdlib>
+#include <cstring>
 
 
 namespace hcamd {
@@ -54,6 +56,9 @@ constexpr uint32_t kNullOffset = 0xFFFFu;
 // match in a row start it.
 constexpr int kLz4WalkBlock = 4;
 constexpr int kLz4WalkAfter = 2;
+
+// An LDS address outside every workgroup's allocation (the whole LDS has 160 KiB).
+constexpr uint32_t kLdsNowhere = 0x30000u;
 
 
 __device__ __forceinline__ uint32_t hash_sum(uint32_t key)
@@ -980,35 +985,31 @@ __device__ __forceinline__ uint32_t take_ticket(uint32_t* ticket, uint32_t count
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 }
 
-// Workgroup shape: a chunk's tables (ht_size x (u16 + u8), 48 KiB for 64 KiB
-// chunks; 32 KiB without tags) are the only LDS user and LDS is what limits
-// residency.  The CU allocates LDS in 1280-byte granules, so separate
-// workgroups of one wave each would waste part of its 160 KiB; ONE workgroup
-// of several waves that owns all of it does not.  Each wave of the workgroup
-// owns one pair of tables and takes chunks from a global ticket counter until
-// the batch is exhausted; the waves never synchronise with each other.
-template <int S, bool TAGS>
-__global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_kernel(
+// What one wave does: chunks from the ticket counter until the batch is
+// exhausted, each through the tables at my_smem.  TAGS: a tag table lies behind
+// the position table.  WALK: match-less stretches take the walk (needs up to
+// 256 vector registers and the accumulation registers to itself, i.e. at most
+// four waves per workgroup).
+template <int S, bool TAGS, bool WALK>
+__device__ __forceinline__ void compress_wave(
     const uint8_t* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     uint8_t* const* __restrict__ out_ptrs,
     size_t* __restrict__ out_bytes,
     const uint32_t ht_size,
-    const uint32_t table_stride,
+    uint8_t* const my_smem,
+    const uint32_t wave,
     const uint32_t batch,
     uint32_t* __restrict__ ticket,
     const uint32_t chunks_per_ticket)
 {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-
   constexpr uint32_t LVM = (12 + S - 1) / S; // last valid match, elements
   constexpr int INV = 3 / S;                 // lanes without a full 4-byte word
   constexpr int NVMAX = kWave - INV;
   constexpr int G = kLz4WalkBlock;
 
   const int lane = lane_id();
-  const uint32_t wave = uniform((uint32_t)(threadIdx.x >> 6));
-  uint8_t* const my_smem = smem + wave * table_stride;
+
   const uint32_t hmask = ht_size - 1;
   Tables<TAGS> T;
   T.pos = reinterpret_cast<uint16_t*>(my_smem);
@@ -1023,11 +1024,13 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   WL.sig = sig < (uint32_t)NVMAX ? sig : 31u;
   WL.never = (NVMAX == 64 && sig == 63u) ? 0x10000u : 0u;
   WL.counts = (sig < (uint32_t)NVMAX && sig != 31u) ? ~0u : 0u;
-  // behind the tables (lz4_compress_lds_bytes); as vector registers the
-  // compiler cannot re-make from the scalar at every use
+  // where the stores of lanes that must not store go: an LDS address beyond
+  // all a workgroup can own -- the hardware drops them (tests/test_hw_probes.py)
+  // and the tables can fill the 160 KiB to the last byte.  (As vector
+  // registers the compiler cannot re-make from a constant at every use.)
   asm volatile("v_mov_b32_e32 %0, %2\n\tv_add_u32_e32 %1, 2, %0"
                : "=&v"(WL.scratch_pos), "=v"(WL.scratch_tag)
-               : "s"((T.pos_lds + ht_size * (TAGS ? 3u : 2u) + 1u) & ~1u));
+               : "s"(kLdsNowhere));
   const uint32_t rev_lane = 63u - (uint32_t)lane;
   const int rev_addr4 = (int)(rev_lane * 4u);
 
@@ -1074,7 +1077,7 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
 
   uint32_t token_start = 0; // first element not yet written out
   while (d < L) {
-    if (cold >= kLz4WalkAfter && (int)(L - d - LVM) >= 2 * G * NVMAX) {
+    if (WALK && cold >= kLz4WalkAfter && (int)(L - d - LVM) >= 2 * G * NVMAX) {
       // ---- the walk (here: two blocks of full windows lie ahead)
       bool match;
       d = (len <= 65536u) ? walk_run<S, G, true>(T, in, d, L, WL, hmask, last_word, match)
@@ -1123,6 +1126,104 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
   if (!ticket)
     break;
  } // next ticket
+}
+
+// Workgroup shapes.  A chunk's tables (ht_size x u16, + ht_size x u8 of tags;
+// 32 / 48 KiB for 64 KiB chunks) are the only LDS user and LDS is what limits
+// residency; the CU hands LDS out in 1280-byte granules, so ONE workgroup that
+// owns all 160 KiB holds more tables than several small ones.  Each wave owns
+// one set of tables and takes chunks from a global ticket counter until the
+// batch is exhausted; the waves never synchronise with each other.
+//   "mix"   up to four waves, the first n_tagged of them with a tag table
+//           (64 KiB chunks: two with, two without = 160 KiB to the byte), all
+//           with the walk: the shape for data with match-less stretches;
+//   "flat"  five waves, no tags, no walk (128 vector registers): the most
+//           chunks in flight, for data that has a match in nearly every window.
+// `mode` (may be null) points at the two counters of the sampling kernel: a
+// kernel whose shape is not the one they call for leaves at once.
+constexpr uint32_t kModeMix = 1, kModeFlat = 2;
+
+// {words that repeated, words looked at} -> shape
+__device__ __forceinline__ uint32_t sampled_mode(const uint32_t* counters)
+{
+  const uint32_t repeats = uniform(counters[0]), looked = uniform(counters[1]);
+  return (looked != 0 && repeats * 4u > looked) ? kModeFlat : kModeMix;
+}
+
+template <int S>
+__global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_kernel_mix(
+    const uint8_t* const* __restrict__ in_ptrs, const size_t* __restrict__ in_bytes,
+    uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ out_bytes,
+    const uint32_t ht_size, const uint32_t n_tagged, const uint32_t stride_tagged, const uint32_t stride_plain,
+    const uint32_t batch, uint32_t* __restrict__ ticket, const uint32_t chunks_per_ticket,
+    const uint32_t* __restrict__ mode)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (mode && sampled_mode(mode) != kModeMix)
+    return;
+  const uint32_t wave = uniform((uint32_t)(threadIdx.x >> 6));
+  if (wave < n_tagged)
+    compress_wave<S, true, true>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, smem + wave * stride_tagged,
+                                 wave, batch, ticket, chunks_per_ticket);
+  else
+    compress_wave<S, false, true>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size,
+                                  smem + n_tagged * stride_tagged + (wave - n_tagged) * stride_plain, wave, batch,
+                                  ticket, chunks_per_ticket);
+}
+
+template <int S>
+__global__ __launch_bounds__(kLz4FlatWavesPerGroup * kWave) void lz4_compress_kernel_flat(
+    const uint8_t* const* __restrict__ in_ptrs, const size_t* __restrict__ in_bytes,
+    uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ out_bytes,
+    const uint32_t ht_size, const uint32_t stride_plain,
+    const uint32_t batch, uint32_t* __restrict__ ticket, const uint32_t chunks_per_ticket,
+    const uint32_t* __restrict__ mode)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (mode && sampled_mode(mode) != kModeFlat)
+    return;
+  const uint32_t wave = uniform((uint32_t)(threadIdx.x >> 6));
+  compress_wave<S, false, false>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, smem + wave * stride_plain, wave,
+                                 batch, ticket, chunks_per_ticket);
+}
+
+// Which shape suits the data: kSampleChunks chunks spread over the batch (one
+// wave each) have kSampleBytes from their middle looked at, and the 4-byte
+// words there (one per byte position) counted that hash to a slot an earlier
+// word of the same sample has hashed to: about n / (2 x 16384) of them for
+// data without repeats, most of them for data LZ4 compresses.  Only speed
+// depends on the answer, never the compressed bytes.
+constexpr int kSampleChunks = 64;
+constexpr uint32_t kSampleBytes = 2048;
+
+__global__ __launch_bounds__(kWave) void lz4_sample_kernel(
+    const uint8_t* const* __restrict__ in_ptrs, const size_t* __restrict__ in_bytes, const uint32_t batch,
+    uint32_t* __restrict__ counters)
+{
+  __shared__ uint32_t seen[16384 / 32];
+  const int lane = lane_id();
+  const uint32_t chunk = (uint32_t)(((uint64_t)batch * blockIdx.x) / gridDim.x);
+  cgptr in = to_global(uniform_ptr(in_ptrs[chunk]));
+  const uint32_t len = uniform((uint32_t)in_bytes[chunk]);
+  if (len < 64)
+    return;
+  const uint32_t n = min(kSampleBytes, len - 4u);
+  const uint32_t from = (len - 4u - n) / 2;
+  for (int i = lane; i < 16384 / 32; i += kWave)
+    seen[i] = 0;
+  __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): one wave, LDS operations in order
+  uint32_t repeats = 0;
+  for (uint32_t p = (uint32_t)lane; p < n; p += kWave) {
+    const uint32_t h = hash_sum(load_u32_any(in + from + p)) & 16383u;
+    const uint32_t old = atomicOr(&seen[h >> 5], 1u << (h & 31u));
+    repeats += (old >> (h & 31u)) & 1u;
+  }
+  for (int o = 32; o > 0; o >>= 1)
+    repeats += __shfl_xor(repeats, o);
+  if (lane == 0) {
+    atomicAdd(&counters[0], repeats);
+    atomicAdd(&counters[1], n);
+  }
 }
 
 // --------------------------------------------------------------------------
@@ -1350,12 +1451,6 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
 
 // ---- launchers -----------------------------------------------------------
 
-size_t lz4_compress_lds_bytes(uint32_t ht_size, bool tags)
-{
-  // position table, tag table, 4 bytes of scratch (WalkLanes::scratch_*)
-  return (ht_size * (tags ? 3u : 2u) + 4u + 15) & ~15u;
-}
-
 namespace {
 
 // Per-device facts and one-time setup, looked up by the calling thread's
@@ -1389,17 +1484,22 @@ int num_cus_of_current_device()
   return n;
 }
 
-typedef void (*CompressKernel)(
-    const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t);
+typedef void (*MixKernel)(
+    const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t, uint32_t,
+    uint32_t, uint32_t*, uint32_t, const uint32_t*);
+typedef void (*FlatKernel)(
+    const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t, uint32_t*,
+    uint32_t, const uint32_t*);
 
-// the kernel for element size `elem_size` (1, 2 or 4 bytes) with or without tag tables
-CompressKernel compress_kernel_for(int elem_size, bool tags)
+MixKernel mix_kernel_for(int elem_size)
 {
-  switch (elem_size) {
-  case 1: return tags ? lz4_compress_kernel<1, true> : lz4_compress_kernel<1, false>;
-  case 2: return tags ? lz4_compress_kernel<2, true> : lz4_compress_kernel<2, false>;
-  default: return tags ? lz4_compress_kernel<4, true> : lz4_compress_kernel<4, false>;
-  }
+  return elem_size == 1 ? lz4_compress_kernel_mix<1> : elem_size == 2 ? lz4_compress_kernel_mix<2>
+                                                                      : lz4_compress_kernel_mix<4>;
+}
+FlatKernel flat_kernel_for(int elem_size)
+{
+  return elem_size == 1 ? lz4_compress_kernel_flat<1> : elem_size == 2 ? lz4_compress_kernel_flat<2>
+                                                                       : lz4_compress_kernel_flat<4>;
 }
 
 // more than 64 KiB of dynamic LDS has to be asked for, once per kernel and device
@@ -1414,63 +1514,156 @@ hipError_t raise_dynamic_lds_limit()
   if (state < 0)
     return (hipError_t)(-state);
   hipError_t r = hipSuccess;
-  for (int es = 1; es <= 4 && r == hipSuccess; es *= 2)
-    for (int tags = 0; tags < 2 && r == hipSuccess; ++tags)
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(compress_kernel_for(es, tags != 0)),
+  for (int es = 1; es <= 4 && r == hipSuccess; es *= 2) {
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(mix_kernel_for(es)),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (r == hipSuccess)
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_kernel_for(es)),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
   g_lds_raised[dev].store(r == hipSuccess ? 1 : -(int)r, std::memory_order_release);
   return r;
 }
 
+constexpr uint32_t kLdsPerCu = 160u * 1024u;
+constexpr uint32_t kLdsGranule = 1280u; // the CU hands LDS out in these (scripts/probes/lds_occupancy.hip)
+
+uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+
+// persistent workgroups: enough to occupy every CU; late ones find the ticket
+// counter exhausted and leave at once
+void set_groups(Lz4CompressShape& sh, size_t batch)
+{
+  const uint32_t w = sh.waves();
+  uint32_t per_cu = kLdsPerCu / round_up(sh.lds_bytes, kLdsGranule);
+  if (per_cu > 8)
+    per_cu = 8;
+  if (per_cu * w > 32)
+    per_cu = 32 / w;
+  const size_t want = (batch + w - 1) / w;
+  const size_t cap = (size_t)num_cus_of_current_device() * per_cu;
+  sh.groups = (uint32_t)(want < cap ? want : cap);
+}
+
 } // namespace
 
-Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch, bool tags)
+Lz4CompressShape lz4_compress_shape_mix(uint32_t ht_size, size_t batch)
 {
-  const int num_cus = num_cus_of_current_device();
-  constexpr uint32_t kLdsPerCu = 160u * 1024u;
   Lz4CompressShape sh;
-  sh.table_stride = (uint32_t)lz4_compress_lds_bytes(ht_size, tags);
-  uint32_t w = kLdsPerCu / sh.table_stride;
-  if (w > (uint32_t)kLz4MaxWavesPerGroup)
-    w = kLz4MaxWavesPerGroup;
+  sh.stride_tagged = round_up(ht_size * 3u, 16u);
+  sh.stride_plain = round_up(ht_size * 2u, 16u);
+  // most waves per CU first (workgroups of g waves, as many as fit), then
+  // most of them with tags
+  uint32_t best_waves = 0, best_tagged = 0;
+  sh.tagged = 1;
+  sh.plain = 0;
+  for (uint32_t g = kLz4MaxWavesPerGroup; g >= 1; --g) {
+    if ((size_t)g > batch && g > 1)
+      continue;
+    for (uint32_t t = g;; --t) {
+      const uint32_t lds = t * sh.stride_tagged + (g - t) * sh.stride_plain;
+      if (lds <= kLdsPerCu) {
+        uint32_t per_cu = kLdsPerCu / round_up(lds, kLdsGranule);
+        if (per_cu > 8)
+          per_cu = 8;
+        const uint32_t waves = g * per_cu, tagged = t * per_cu;
+        if (waves > best_waves || (waves == best_waves && tagged > best_tagged)) {
+          best_waves = waves;
+          best_tagged = tagged;
+          sh.tagged = t;
+          sh.plain = g - t;
+        }
+        break; // fewer tags in a group of this size cannot be better
+      }
+      if (t == 0)
+        break;
+    }
+  }
+  sh.lds_bytes = sh.tagged * sh.stride_tagged + sh.plain * sh.stride_plain;
+  set_groups(sh, batch);
+  return sh;
+}
+
+Lz4CompressShape lz4_compress_shape_flat(uint32_t ht_size, size_t batch)
+{
+  Lz4CompressShape sh;
+  sh.stride_tagged = 0;
+  sh.stride_plain = round_up(ht_size * 2u, 16u);
+  sh.tagged = 0;
+  uint32_t w = kLdsPerCu / sh.stride_plain;
+  if (w > (uint32_t)kLz4FlatWavesPerGroup)
+    w = kLz4FlatWavesPerGroup;
   if ((size_t)w > batch)
     w = (uint32_t)batch;
-  sh.waves = w;
-  sh.lds_bytes = w * sh.table_stride;
-  // enough workgroups to occupy every CU; late ones find the ticket counter
-  // exhausted and leave at once
-  const size_t per_cu = kLdsPerCu / sh.lds_bytes;
-  const size_t want = (batch + w - 1) / w;
-  const size_t cap = (size_t)num_cus * (per_cu > 8 ? 8 : per_cu);
-  sh.groups = (uint32_t)(want < cap ? want : cap);
+  sh.plain = w;
+  sh.lds_bytes = w * sh.stride_plain;
+  set_groups(sh, batch);
   return sh;
+}
+
+Lz4Mode lz4_mode_from_environment()
+{
+  static const Lz4Mode mode = [] {
+    const char* e = std::getenv("HIPCOMP_LZ4_SHAPE");
+    if (e && std::strcmp(e, "mix") == 0)
+      return Lz4Mode::Mix;
+    if (e && std::strcmp(e, "flat") == 0)
+      return Lz4Mode::Flat;
+    return Lz4Mode::Auto;
+  }();
+  return mode;
 }
 
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, uint32_t* ticket, size_t max_chunk_bytes, bool tags, hipStream_t stream)
+    size_t batch, int elem_size, uint32_t* scratch, size_t max_chunk_bytes, Lz4Mode mode, hipStream_t stream)
 {
-  const Lz4CompressShape sh = lz4_compress_shape(ht_size, batch, tags);
-  // about 16 KiB of input per ticket, but at least 4 tickets per wave so
-  // that the last ones even out the load
-  uint32_t per_ticket = 1;
-  const size_t all_waves = (size_t)sh.groups * sh.waves;
-  while (per_ticket < 64 && (size_t)per_ticket * (max_chunk_bytes ? max_chunk_bytes : 1) < 16384
-         && (size_t)per_ticket * 2 * 4 * all_waves <= batch)
-    per_ticket *= 2;
-  // ticket == nullptr: no persistent workgroups, one chunk per wave
-  const dim3 grid(ticket ? sh.groups : (unsigned)((batch + sh.waves - 1) / sh.waves)), block(sh.waves * kWave);
-  if (ticket) {
-    const hipError_t e = hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess)
-      return e;
-  }
+  const Lz4CompressShape mix = lz4_compress_shape_mix(ht_size, batch);
+  const Lz4CompressShape flat = lz4_compress_shape_flat(ht_size, batch);
+  // the flat shape only pays when it holds more chunks per CU and the batch
+  // fills the chip; it needs the ticket counter
+  const bool flat_possible = scratch != nullptr && flat.waves() * flat.groups > mix.waves() * mix.groups
+                             && batch >= (size_t)4 * mix.groups * mix.waves();
+  if (mode == Lz4Mode::Auto && !flat_possible)
+    mode = Lz4Mode::Mix;
+  if (mode == Lz4Mode::Flat && scratch == nullptr) // (forced by the environment: any batch that has a ticket counter)
+    mode = Lz4Mode::Mix;
   const hipError_t raised = raise_dynamic_lds_limit();
   if (raised != hipSuccess)
     return raised;
-  compress_kernel_for(elem_size, tags)<<<grid, block, sh.lds_bytes, stream>>>(
-      in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, sh.table_stride, (uint32_t)batch, ticket, per_ticket);
+  uint32_t* ticket = scratch;
+  const uint32_t* chosen = nullptr; // the sampling kernel's counters, if it runs
+  if (scratch) {
+    const hipError_t e = hipMemsetAsync(scratch, 0, 3 * sizeof(uint32_t), stream);
+    if (e != hipSuccess)
+      return e;
+    if (mode == Lz4Mode::Auto) {
+      lz4_sample_kernel<<<kSampleChunks, kWave, 0, stream>>>(in_ptrs, in_bytes, (uint32_t)batch, scratch + 1);
+      chosen = scratch + 1;
+    }
+  }
+  // about 16 KiB of input per ticket, but at least 4 tickets per wave so
+  // that the last ones even out the load
+  auto chunks_per_ticket = [&](const Lz4CompressShape& sh) {
+    uint32_t per_ticket = 1;
+    const size_t all_waves = (size_t)sh.groups * sh.waves();
+    while (per_ticket < 64 && (size_t)per_ticket * (max_chunk_bytes ? max_chunk_bytes : 1) < 16384
+           && (size_t)per_ticket * 2 * 4 * all_waves <= batch)
+      per_ticket *= 2;
+    return per_ticket;
+  };
+  if (mode != Lz4Mode::Flat) {
+    // ticket == nullptr: no persistent workgroups, one chunk per wave
+    const dim3 grid(ticket ? mix.groups : (unsigned)((batch + mix.waves() - 1) / mix.waves()));
+    mix_kernel_for(elem_size)<<<grid, dim3(mix.waves() * kWave), mix.lds_bytes, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
+        (uint32_t)batch, ticket, chunks_per_ticket(mix), chosen);
+  }
+  if (mode != Lz4Mode::Mix)
+    flat_kernel_for(elem_size)<<<dim3(flat.groups), dim3(flat.waves() * kWave), flat.lds_bytes, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, flat.stride_plain, (uint32_t)batch, ticket,
+        chunks_per_ticket(flat), chosen);
   return hipSuccess;
 }
 

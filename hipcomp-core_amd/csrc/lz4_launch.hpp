@@ -9,35 +9,42 @@
 
 namespace hcamd {
 
-// LDS bytes of one chunk's tables: positions (u16 per slot) and, with `tags`,
-// the tag table (u8 per slot) that spares the encoder most candidate fetches.
-size_t lz4_compress_lds_bytes(uint32_t ht_size, bool tags);
-
-// Most waves (= chunks in flight) one compression workgroup holds.  Four (one
-// per SIMD): the kernel may then use up to 256 vector registers and keeps
-// clear of the accumulation registers, which its walk uses by name
-// (lz4_kernels.hip, HC_WALK_AGPRS; tests/test_abi_cpu.py checks the build).
+// Most waves (= chunks in flight) one compression workgroup of the "mix" shape
+// holds.  Four (one per SIMD): the kernel may then use up to 256 vector
+// registers and keeps clear of the accumulation registers, which its walk uses
+// by name (lz4_kernels.hip, HC_WALK_AGPRS; tests/test_build_guards_cpu.py
+// checks the build).  The "flat" shape (no walk) holds five.
 constexpr int kLz4MaxWavesPerGroup = 4;
+constexpr int kLz4FlatWavesPerGroup = 5;
 
-// Launch shape of the compression kernel: `waves` chunks in flight per
-// workgroup, each with its own `table_stride` bytes of LDS.
+// Launch shape of a compression kernel: per workgroup `tagged` waves whose
+// chunk has a tag table behind its position table and `plain` waves without.
 struct Lz4CompressShape
 {
-  uint32_t waves;
-  uint32_t table_stride;
-  uint32_t lds_bytes;
-  uint32_t groups;
+  uint32_t tagged, plain;
+  uint32_t stride_tagged, stride_plain; // LDS bytes of one wave's tables
+  uint32_t lds_bytes;                   // of the workgroup
+  uint32_t groups;                      // persistent workgroups
+  uint32_t waves() const { return tagged + plain; }
 };
-Lz4CompressShape lz4_compress_shape(uint32_t ht_size, size_t batch, bool tags);
+// the shape for data with match-less stretches / for data with matches everywhere
+Lz4CompressShape lz4_compress_shape_mix(uint32_t ht_size, size_t batch);
+Lz4CompressShape lz4_compress_shape_flat(uint32_t ht_size, size_t batch);
 
-// `ticket` is one zero-initialised-by-the-launcher uint32 in device memory
-// (in the caller's temp buffer) from which the waves of the persistent
-// workgroups draw chunk numbers; nullptr = one chunk per wave, as many
-// workgroups as that takes.  batch must be > 0 and < 2^31.
+enum class Lz4Mode { Auto, Mix, Flat };
+// HIPCOMP_LZ4_SHAPE = auto | mix | flat (read once; default auto).  A
+// measurement / test knob: the compressed bytes do not depend on it.
+Lz4Mode lz4_mode_from_environment();
+
+// `scratch` points at three zero-initialised-by-the-launcher uint32 in device
+// memory (the head of the caller's temp buffer): the ticket counter from which
+// the waves of the persistent workgroups draw chunk numbers, and the two
+// counters of the sampling kernel that pick the shape.  nullptr = one chunk per wave,
+// as many workgroups as that takes, "mix" shape.  batch must be > 0 and < 2^31.
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, uint32_t* ticket, size_t max_chunk_bytes, bool tags, hipStream_t stream);
+    size_t batch, int elem_size, uint32_t* scratch, size_t max_chunk_bytes, Lz4Mode mode, hipStream_t stream);
 
 // write_out == false: parse-only pass that reports sizes.
 void lz4_launch_decompress(

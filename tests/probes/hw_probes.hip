@@ -56,6 +56,37 @@ extern "C" int probe_lds_store_byte(uint16_t* out, const int* slot, unsigned lon
   return (int)hipGetLastError();
 }
 
+// (4) LDS stores to an address beyond everything a workgroup can own (the
+//     encoder's walk sends the stores of lanes that must not store there when
+//     its tables fill the whole 160 KiB): dropped, nothing else changes; a read
+//     from there returns 0.
+__global__ void k_lds_out_of_range(uint32_t* out, int nwords, uint32_t far_addr)
+{
+  extern __shared__ uint32_t words[];
+  const int t = threadIdx.x;
+  for (int i = t; i < nwords; i += 64)
+    words[i] = 0xA5000000u + (uint32_t)i;
+  __syncthreads();
+  const uint32_t a = far_addr + 2u * (uint32_t)t;
+  uint32_t back = 0x12345678u;
+  asm volatile("ds_write_b16 %1, %2\n\tds_write_b8 %1, %2 offset:1\n\tds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+               : "=v"(back) : "v"(a), "v"(0xBEEFu + (uint32_t)t) : "memory");
+  __syncthreads();
+  for (int i = t; i < nwords; i += 64)
+    out[i] = words[i];
+  out[nwords + t] = back;
+}
+
+extern "C" int probe_lds_out_of_range(uint32_t* out, int nwords, uint32_t far_addr, hipStream_t st)
+{
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds_out_of_range),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess)
+    return (int)e;
+  k_lds_out_of_range<<<1, 64, nwords * 4, st>>>(out, nwords, far_addr);
+  return (int)hipGetLastError();
+}
+
 extern "C" int probe_global_store_short(uint16_t* out, const int* slot, unsigned long long mask, hipStream_t st)
 {
   k_global_store_short<<<1, 64, 0, st>>>(out, slot, mask);

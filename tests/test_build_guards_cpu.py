@@ -24,8 +24,15 @@ def test_compiler_leaves_the_accumulation_registers_alone(tmp_path):
                     "--cuda-device-only", src, "-o", str(out)], check=True, capture_output=True)
     text = out.read_text()
     assert "v_accvgpr_write" not in text
-    agprs = dict(re.findall(r"\.set (\S*lz4_compress_kernel\S*)\.num_agpr, (\d+)", text))
-    assert len(agprs) == 6                       # element size 1, 2, 4 x with / without tag tables
-    assert set(agprs.values()) == {"24"}
-    spills = re.findall(r"\.set \S*lz4_compress_kernel\S*\.private_seg_size, (\d+)", text)
+    assert "_d16" not in text                    # table entries are read zero-extended (walk_probe relies on it)
+    agprs = dict(re.findall(r"\.set (\S*lz4_compress_kernel_\S*)\.num_agpr, (\d+)", text))
+    vgprs = dict(re.findall(r"\.set (\S*lz4_compress_kernel_\S*)\.num_vgpr, (\d+)", text))
+    mix = [k for k in agprs if "kernel_mix" in k]
+    flat = [k for k in agprs if "kernel_flat" in k]
+    assert len(mix) == 3 and len(flat) == 3      # element size 1, 2, 4
+    assert {agprs[k] for k in mix} == {"24"}     # the walk's own, nothing of the compiler's
+    assert {agprs[k] for k in flat} == {"0"}     # no walk
+    assert all(int(vgprs[k]) <= 128 for k in flat)   # five waves per workgroup = two on one SIMD
+    assert all(int(vgprs[k]) <= 256 for k in mix)
+    spills = re.findall(r"\.set \S*lz4_compress_kernel_\S*\.private_seg_size, (\d+)", text)
     assert spills and set(spills) == {"0"}       # nothing spilled to scratch memory either

@@ -79,3 +79,22 @@ def test_same_address_store_winner(cuda, oracle, space):
                 bad += (w != want)
     print(f"[probe] {space}: {groups} multi-lane groups, {bad} off-rule")
     assert groups > 500 and bad == 0
+
+
+@pytest.mark.parametrize("nwords", [40960, 12288, 256])
+def test_lds_store_beyond_the_allocation_is_dropped(cuda, nwords):
+    """The LZ4 encoder's walk sends the table stores of lanes that must not
+    store to LDS address 0x30000, beyond the 160 KiB a workgroup can own
+    (lz4_kernels.hip: kLdsNowhere), when its tables leave no byte for a scratch
+    slot: the hardware drops such stores and reads from there return 0."""
+    import torch
+    lib = _lib()
+    out = torch.zeros(nwords + 64, dtype=torch.int32, device=cuda)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.probe_lds_out_of_range(ctypes.c_void_p(out.data_ptr()), nwords, ctypes.c_uint32(0x30000), st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype("uint32")
+    import numpy as np
+    assert (got[:nwords] == 0xA5000000 + np.arange(nwords, dtype=np.uint32)).all()   # nothing inside changed
+    assert (got[nwords:] == 0).all()                                                # reads from nowhere: 0

@@ -19,21 +19,35 @@ def _declared_symbols():
     return names
 
 
+def _declared_primitives():
+    text = open(os.path.join(ROOT, "include", "hipcomp", "primitives.h")).read()
+    return set(re.findall(r"hipcompStatus_t\s+(hipcomp\w+)\s*\(", text))
+
+
 def test_library_exports_exactly_the_declared_abi(hc):
     lib = hc.default_library()
-    out = subprocess.run(["nm", "-D", "--defined-only", lib.path], capture_output=True, text=True, check=True).stdout
-    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    out = subprocess.run(["nm", "-D", "--defined-only", "-C", lib.path], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split(" T ", 1)[1].strip() for ln in out.splitlines() if " T " in ln}
     declared = _declared_symbols()
     built = {s for s in declared if any(s.startswith(f"hipcompBatched{c}") for c in lib.codecs)}
     assert built <= exported, sorted(built - exported)
-    assert exported <= declared, sorted(exported - declared)
     assert len(declared) == 18
+    prims = _declared_primitives()
+    assert len(prims) == 7 and prims <= exported
+    # the C++ classes of hipcomp/primitives.hpp (reference src/{RunLengthEncodeGPU,DeltaGPU,BitPackGPU}.h)
+    classes = {e.split("(")[0] for e in exported if e.startswith("hipcomp::")}
+    assert classes == {"hipcomp::RunLengthEncodeGPU::compress", "hipcomp::RunLengthEncodeGPU::compressDownstream",
+                       "hipcomp::RunLengthEncodeGPU::requiredWorkspaceSize", "hipcomp::DeltaGPU::compress",
+                       "hipcomp::DeltaGPU::requiredWorkspaceSize", "hipcomp::BitPackGPU::compress",
+                       "hipcomp::BitPackGPU::requiredWorkspaceSize"}
+    others = {e for e in exported if not e.startswith("hipcomp::")}
+    assert others <= declared | prims, sorted(others - declared - prims)
 
 
 def test_headers_compile_as_c(tmp_path):
     """The public headers are C-clean (the reference proves this with its C harness)."""
     src = tmp_path / "t.c"
-    src.write_text('#include "hipcomp/lz4.h"\n#include "hipcomp/snappy.h"\n#include "hipcomp/cascaded.h"\n'
+    src.write_text('#include "hipcomp/lz4.h"\n#include "hipcomp/snappy.h"\n#include "hipcomp/cascaded.h"\n#include "hipcomp/primitives.h"\n'
                    "int main(void){hipcompBatchedLZ4Opts_t o = hipcompBatchedLZ4DefaultOpts;"
                    "hipcompBatchedCascadedOpts_t c = hipcompBatchedCascadedDefaultOpts;"
                    "hipcompBatchedSnappyOpts_t s = hipcompBatchedSnappyDefaultOpts;"

@@ -24,6 +24,11 @@ def _declared_primitives():
     return set(re.findall(r"hipcompStatus_t\s+(hipcomp\w+)\s*\(", text))
 
 
+def _declared_interop():
+    text = open(os.path.join(ROOT, "include", "hipcomp", "lz4_interop.h")).read()
+    return set(re.findall(r"(?:hipcompStatus_t|size_t)\s+(hipcompLZ4Frame\w+)\s*\(", text))
+
+
 def test_library_exports_exactly_the_declared_abi(hc):
     lib = hc.default_library()
     out = subprocess.run(["nm", "-D", "--defined-only", "-C", lib.path], capture_output=True, text=True, check=True).stdout
@@ -40,14 +45,16 @@ def test_library_exports_exactly_the_declared_abi(hc):
                        "hipcomp::RunLengthEncodeGPU::requiredWorkspaceSize", "hipcomp::DeltaGPU::compress",
                        "hipcomp::DeltaGPU::requiredWorkspaceSize", "hipcomp::BitPackGPU::compress",
                        "hipcomp::BitPackGPU::requiredWorkspaceSize"}
+    interop = _declared_interop()
+    assert len(interop) == 3 and interop <= exported
     others = {e for e in exported if not e.startswith("hipcomp::")}
-    assert others <= declared | prims, sorted(others - declared - prims)
+    assert others <= declared | prims | interop, sorted(others - declared - prims - interop)
 
 
 def test_headers_compile_as_c(tmp_path):
     """The public headers are C-clean (the reference proves this with its C harness)."""
     src = tmp_path / "t.c"
-    src.write_text('#include "hipcomp/lz4.h"\n#include "hipcomp/snappy.h"\n#include "hipcomp/cascaded.h"\n#include "hipcomp/primitives.h"\n'
+    src.write_text('#include "hipcomp/lz4.h"\n#include "hipcomp/snappy.h"\n#include "hipcomp/cascaded.h"\n#include "hipcomp/primitives.h"\n#include "hipcomp/lz4_interop.h"\n'
                    "int main(void){hipcompBatchedLZ4Opts_t o = hipcompBatchedLZ4DefaultOpts;"
                    "hipcompBatchedCascadedOpts_t c = hipcompBatchedCascadedDefaultOpts;"
                    "hipcompBatchedSnappyOpts_t s = hipcompBatchedSnappyDefaultOpts;"

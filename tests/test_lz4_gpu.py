@@ -322,3 +322,18 @@ def test_maximum_chunk_size_16MiB(hc, oracle, cuda):
     dec, actual, statuses = codec.decompress(mine, n)
     assert statuses.cpu().tolist() == [0] and actual.cpu().tolist() == [n]
     assert dec.to_host_chunks()[0] == data
+
+
+def test_cpu_interop_example(cuda):
+    """examples/lz4_cpu_interop.c: GPU-compressed chunks decode with liblz4 block by block
+    and as one LZ4 frame; liblz4-compressed chunks decompress on the GPU."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "lz4_cpu_interop")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    for args in (["37", "65536"], ["300", "4000"]):
+        r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=120)
+        if r.returncode == 77:
+            pytest.skip("no liblz4 on this box")
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.count("OK") == 3

@@ -24,6 +24,11 @@ def _declared_primitives():
     return set(re.findall(r"hipcompStatus_t\s+(hipcomp\w+)\s*\(", text))
 
 
+def _declared_hlif():
+    text = open(os.path.join(ROOT, "include", "hipcomp", "hlif.h")).read()
+    return set(re.findall(r"hipcompStatus_t\s+(hipcompHlif\w+)\s*\(", text))
+
+
 def _declared_interop():
     text = open(os.path.join(ROOT, "include", "hipcomp", "lz4_interop.h")).read()
     return set(re.findall(r"(?:hipcompStatus_t|size_t)\s+(hipcompLZ4Frame\w+)\s*\(", text))
@@ -41,20 +46,29 @@ def test_library_exports_exactly_the_declared_abi(hc):
     assert len(prims) == 7 and prims <= exported
     # the C++ classes of hipcomp/primitives.hpp (reference src/{RunLengthEncodeGPU,DeltaGPU,BitPackGPU}.h)
     classes = {e.split("(")[0] for e in exported if e.startswith("hipcomp::")}
+    hlif_classes = {c for c in classes if c.split("::")[1] in ("LZ4Manager", "CompressionConfig", "DecompressionConfig")}
+    assert {"hipcomp::LZ4Manager::compress", "hipcomp::LZ4Manager::decompress", "hipcomp::LZ4Manager::LZ4Manager",
+            "hipcomp::LZ4Manager::configure_compression", "hipcomp::LZ4Manager::configure_decompression",
+            "hipcomp::LZ4Manager::get_compressed_output_size", "hipcomp::LZ4Manager::set_scratch_buffer",
+            "hipcomp::LZ4Manager::get_required_scratch_buffer_size", "hipcomp::CompressionConfig::get_status",
+            "hipcomp::DecompressionConfig::get_status"} <= hlif_classes
+    classes -= hlif_classes
     assert classes == {"hipcomp::RunLengthEncodeGPU::compress", "hipcomp::RunLengthEncodeGPU::compressDownstream",
                        "hipcomp::RunLengthEncodeGPU::requiredWorkspaceSize", "hipcomp::DeltaGPU::compress",
                        "hipcomp::DeltaGPU::requiredWorkspaceSize", "hipcomp::BitPackGPU::compress",
                        "hipcomp::BitPackGPU::requiredWorkspaceSize"}
     interop = _declared_interop()
     assert len(interop) == 3 and interop <= exported
-    others = {e for e in exported if not e.startswith("hipcomp::")}
-    assert others <= declared | prims | interop, sorted(others - declared - prims - interop)
+    hlif = _declared_hlif()
+    assert len(hlif) == 9 and hlif <= exported
+    others = {e for e in exported if not e.startswith("hipcomp::") and not e.startswith(("vtable for", "typeinfo"))}
+    assert others <= declared | prims | interop | hlif, sorted(others - declared - prims - interop - hlif)
 
 
 def test_headers_compile_as_c(tmp_path):
     """The public headers are C-clean (the reference proves this with its C harness)."""
     src = tmp_path / "t.c"
-    src.write_text('#include "hipcomp/lz4.h"\n#include "hipcomp/snappy.h"\n#include "hipcomp/cascaded.h"\n#include "hipcomp/primitives.h"\n#include "hipcomp/lz4_interop.h"\n'
+    src.write_text('#include "hipcomp/lz4.h"\n#include "hipcomp/snappy.h"\n#include "hipcomp/cascaded.h"\n#include "hipcomp/primitives.h"\n#include "hipcomp/lz4_interop.h"\n#include "hipcomp/hlif.h"\n'
                    "int main(void){hipcompBatchedLZ4Opts_t o = hipcompBatchedLZ4DefaultOpts;"
                    "hipcompBatchedCascadedOpts_t c = hipcompBatchedCascadedDefaultOpts;"
                    "hipcompBatchedSnappyOpts_t s = hipcompBatchedSnappyDefaultOpts;"

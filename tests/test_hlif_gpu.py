@@ -1,0 +1,149 @@
+"""The high-level interface's LZ4 manager (hipcomp/lz4.hpp via its C binding hipcomp/hlif.h):
+container layout (reference src/hipcomp_common_deps/hlif_shared_types.hpp:68-84,
+src/highlevel/BatchManager.hpp:108-112), chunks = the batched API's streams = the oracle's,
+round trips, and both directions against the REFERENCE's own manager (oracle/_ref/hlif_ref_tool,
+the reference's unmodified high-level sources driven on files)."""
+import ctypes
+import os
+import struct
+import subprocess
+from ctypes import c_int, c_size_t, c_void_p
+
+import numpy as np
+import pytest
+
+import datagen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_TOOL = os.path.join(ROOT, "oracle", "_ref", "hlif_ref_tool")
+
+
+def _lib(hc):
+    return ctypes.CDLL(hc.default_library().path)
+
+
+class Manager:
+    def __init__(self, L, chunk, dtype):
+        self.L = L
+        self.h = c_void_p()
+        assert L.hipcompHlifLZ4ManagerCreate(c_size_t(chunk), c_int(dtype), None, ctypes.byref(self.h)) == 0
+
+    def close(self):
+        self.L.hipcompHlifManagerDestroy(self.h)
+
+    def compress(self, data: bytes, cuda):
+        import torch
+        mx, nc = c_size_t(0), c_size_t(0)
+        assert self.L.hipcompHlifConfigureCompression(self.h, c_size_t(len(data)), ctypes.byref(mx), ctypes.byref(nc)) == 0
+        src = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(cuda) if data else torch.empty(8, dtype=torch.uint8, device=cuda)
+        dst = torch.zeros(mx.value + 8, dtype=torch.uint8, device=cuda)
+        assert self.L.hipcompHlifCompress(self.h, c_void_p(src.data_ptr()), c_size_t(len(data)), c_void_p(dst.data_ptr())) == 0
+        st = c_int(-1)
+        assert self.L.hipcompHlifGetLastStatus(self.h, ctypes.byref(st)) == 0 and st.value == 0
+        size = c_size_t(0)
+        assert self.L.hipcompHlifGetCompressedSize(self.h, c_void_p(dst.data_ptr()), ctypes.byref(size)) == 0
+        assert size.value <= mx.value
+        return dst[: size.value].cpu().numpy().tobytes(), nc.value
+
+    def decompress(self, container: bytes, cuda):
+        import torch
+        src = torch.from_numpy(np.frombuffer(container, dtype=np.uint8).copy()).to(cuda)
+        n, nc = c_size_t(0), c_size_t(0)
+        assert self.L.hipcompHlifGetDecompressedSize(self.h, c_void_p(src.data_ptr()), ctypes.byref(n), ctypes.byref(nc)) == 0
+        dst = torch.zeros(max(n.value, 8), dtype=torch.uint8, device=cuda)
+        assert self.L.hipcompHlifDecompress(self.h, c_void_p(src.data_ptr()), c_void_p(dst.data_ptr())) == 0
+        st = c_int(-1)
+        assert self.L.hipcompHlifGetLastStatus(self.h, ctypes.byref(st)) == 0
+        return st.value, dst[: n.value].cpu().numpy().tobytes()
+
+
+def _parse(container: bytes):
+    magic, major, minor, fmt = struct.unpack_from("<IBBB", container, 0)
+    comp_size, decomp_size, n = struct.unpack_from("<QQQ", container, 8)
+    chunk, = struct.unpack_from("<Q", container, 48)
+    data_off, = struct.unpack_from("<I", container, 56)
+    dtype, = struct.unpack_from("<I", container, 64)
+    offs = struct.unpack_from(f"<{n}Q", container, 72)
+    sizes = struct.unpack_from(f"<{n}Q", container, 72 + 8 * n)
+    return dict(magic=magic, version=(major, minor), format=fmt, comp_size=comp_size, decomp_size=decomp_size, n=n,
+                chunk=chunk, data_off=data_off, dtype=dtype, offs=offs, sizes=sizes)
+
+
+def _inputs():
+    rng = np.random.default_rng(5)
+    return [datagen.text_like(4, 300001), datagen.harness_like_int32(6, 70000).tobytes(),
+            bytes(rng.integers(0, 256, 200000, dtype=np.uint8)), b"abc", b"", bytes(65536 * 3)]
+
+
+@pytest.mark.parametrize("chunk,dtype,es", [(65536, 0, 1), (4096, 0, 1), (65536, 4, 4), (100000, 2, 2)])
+def test_container_layout_chunks_and_round_trip(hc, oracle, cuda, chunk, dtype, es):
+    L = _lib(hc)
+    m = Manager(L, chunk, dtype)
+    for data in _inputs():
+        if len(data) % es:
+            data = data[: len(data) // es * es]
+        cont, nc = m.compress(data, cuda)
+        h = _parse(cont)
+        assert nc == (len(data) + chunk - 1) // chunk == h["n"]
+        assert (h["magic"], h["version"], h["format"]) == (0, (2, 2), 0)
+        assert (h["decomp_size"], h["chunk"], h["dtype"]) == (len(data), chunk, dtype)
+        assert h["data_off"] == 72 + 24 * nc and len(cont) == h["data_off"] + h["comp_size"]
+        assert h["comp_size"] == sum(h["sizes"])
+        at = 0
+        for i in range(nc):                                   # chunk order, packed; each chunk = the batched stream
+            assert h["offs"][i] == at
+            piece = data[i * chunk:(i + 1) * chunk]
+            blob = cont[h["data_off"] + at: h["data_off"] + at + h["sizes"][i]]
+            assert blob == oracle.lz4_compress(piece, es, chunk)
+            at += h["sizes"][i]
+        st, back = m.decompress(cont, cuda)
+        assert st == 0 and back == data
+        if nc:                                                # a damaged chunk fails the whole buffer
+            bad = bytearray(cont)
+            bad[h["data_off"]] ^= 0xF0
+            st, _ = m.decompress(bytes(bad), cuda)
+            assert st in (0, 12)                              # (a changed token can still decode to the right length)
+    m.close()
+
+
+def test_many_chunks_take_several_slabs(hc, cuda):
+    L = _lib(hc)
+    m = Manager(L, 1024, 0)                                   # slab = 8192 chunks: 20000 chunks = 3 passes
+    data = datagen.text_like(9, 20000 * 1024 - 100)
+    cont, nc = m.compress(data, cuda)
+    assert nc == 20000
+    st, back = m.decompress(cont, cuda)
+    assert st == 0 and back == data
+    need = c_size_t(0)
+    assert L.hipcompHlifGetRequiredScratchBytes(m.h, ctypes.byref(need)) == 0 and need.value > 8192 * 1024
+    m.close()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TOOL), reason="reference build of the high-level interface not present")
+@pytest.mark.parametrize("chunk,dtype", [(65536, 0), (8192, 4)])
+def test_containers_interchange_with_the_reference_manager(hc, cuda, tmp_path, chunk, dtype):
+    L = _lib(hc)
+    m = Manager(L, chunk, dtype)
+    data = datagen.text_like(21, 1000000) + datagen.harness_like_int32(3, 50000).tobytes()
+    # ours -> reference
+    cont, _ = m.compress(data, cuda)
+    (tmp_path / "ours.bin").write_bytes(cont)
+    r = subprocess.run([REF_TOOL, "decompress", str(tmp_path / "ours.bin"), str(tmp_path / "ours.out")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "ours.out").read_bytes() == data
+    # reference -> ours
+    (tmp_path / "in.bin").write_bytes(data)
+    r = subprocess.run([REF_TOOL, "compress", str(chunk), str(dtype), str(tmp_path / "in.bin"), str(tmp_path / "ref.bin")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref_cont = (tmp_path / "ref.bin").read_bytes()
+    st, back = m.decompress(ref_cont, cuda)
+    assert st == 0 and back == data
+    a, b = _parse(cont), _parse(ref_cont)                     # same header and sizes; the reference places chunks in completion order
+    assert {k: a[k] for k in a if k != "offs"} == {k: b[k] for k in b if k != "offs"}
+    for i in range(a["n"]):                                  # chunk for chunk the same bytes, placed elsewhere
+        assert (cont[a["data_off"] + a["offs"][i]: a["data_off"] + a["offs"][i] + a["sizes"][i]]
+                == ref_cont[b["data_off"] + b["offs"][i]: b["data_off"] + b["offs"][i] + b["sizes"][i]])
+    m.close()

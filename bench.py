@@ -537,15 +537,18 @@ def main():
         srow = measure_row(hc, lib, "Snappy", hc.SnappyOpts(0), text,
                            {"codec": "Snappy", "config": "BASELINE configs[3]: TPC-H lineitem-like text, 1 GiB, 64 KiB chunks"})
         if not args.no_cpu:
-            srow["cpu_baseline"] = cpu_codec_baseline("Snappy", text_host[: 2048 * CHUNK])
+            srow["cpu_baseline"] = cpu_codec_baseline("Snappy", text_host[: 8192 * CHUNK])
         rows.append(srow)
         del text, text_host
         cols = gen_sorted_columns(vc, dev)
         crow = measure_row(hc, lib, "Cascaded", hc.CascadedOpts(4096, hc.hipcompType.UINT, 2, 1, 1), cols,
                            {"codec": "Cascaded", "config": "BASELINE configs[2]: sorted uint32 columns, opts {4096, UINT, 2, 1, 1}"})
         if not args.no_cpu:
-            crow["cpu_baseline"] = cpu_codec_baseline("Cascaded", cols[: 2048 * CHUNK].cpu().numpy())
+            crow["cpu_baseline"] = cpu_codec_baseline("Cascaded", cols[: 8192 * CHUNK].cpu().numpy())
         rows.append(crow)
+        for cb in (8192, 16384):   # opts.chunk_size honoured; 4096 above is the reference's
+            rows.append(measure_row(hc, lib, "Cascaded", hc.CascadedOpts(cb, hc.hipcompType.UINT, 2, 1, 1), cols,
+                                    {"codec": "Cascaded", "config": f"same columns, opts {{{cb}, UINT, 2, 1, 1}}"}))
         del cols
         res["extra_keys"] = rows
     if rank == 0:

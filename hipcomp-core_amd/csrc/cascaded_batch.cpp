@@ -91,7 +91,12 @@ hipcompStatus_t hipcompBatchedCascadedCompressAsync(
       device_uncompressed_bytes,
       reinterpret_cast<uint8_t* const*>(device_compressed_ptrs),
       device_compressed_bytes, batch_size, (int)format_opts.type, s, R, D,
-      format_opts.use_bp ? 1 : 0, stream);
+      format_opts.use_bp ? 1 : 0,
+      // chunk_size: the reference ignores the field (cascaded.h:93-100) and cuts
+      // partitions into 4096-byte sub-chunks; 8192 and 16384 are honoured here,
+      // every other value means the reference's
+      (format_opts.chunk_size == 8192 || format_opts.chunk_size == 16384) ? (uint32_t)format_opts.chunk_size : 4096u,
+      stream);
   std::string why;
   if (!launch_ok("cascaded compression kernel", why))
     return fail(fn, why);

@@ -34,7 +34,11 @@ namespace hcamd {
 
 namespace {
 
-constexpr uint32_t kChunkBytes = 4096;
+// Sub-chunk size CB (a template parameter of the kernels): 4096 is the reference's
+// (CascadedKernels.hiph:88, hard-wired; its opts.chunk_size is "not currently used",
+// cascaded.h:93-100); 8192 and 16384 are honoured here (the 160 KiB
+// of LDS permit them).  Streams with the larger sub-chunks say so in the high nibble
+// of header byte 2 (use_bp, 0 or 1 in the reference): 0 = 4096, 1 = 8192, 2 = 16384.
 constexpr uint32_t kPartMeta = 8;
 #ifndef HC_CASC_WAVES
 #define HC_CASC_WAVES 1 // 10 KiB of LDS per wave: separate blocks pack 14 per CU, 4-wave blocks only 12
@@ -49,25 +53,26 @@ template <> struct UIntOf<8> { typedef uint64_t type; typedef int64_t stype; };
 
 __device__ __forceinline__ uint32_t ru(uint32_t a, uint32_t b) { return (a + b - 1) / b * b; }
 
-__host__ __device__ constexpr uint32_t elem_buf_bytes() { return kChunkBytes + 16; }
+template <int CB>
+__host__ __device__ constexpr uint32_t elem_buf_bytes() { return CB + 16; }
 
-template <int S>
+template <int S, int CB>
 __host__ __device__ constexpr uint32_t wave_lds_bytes()
 {
   // encoder: one element buffer (every layer works in place) + run-count
   // array + 64-byte metadata image
-  return elem_buf_bytes() + (kChunkBytes / S) * 2 + 64;
+  return elem_buf_bytes<CB>() + (CB / S) * 2 + 64;
 }
 
 // decoder: the compressed sub-chunk (metadata + arrays) is staged in LDS,
 // kStageWords 32-bit words per sub-chunk, 8 per lane, loaded one sub-chunk
 // ahead into registers.  Arrays that do not fit are read from HBM directly.
 constexpr uint32_t kStageWords = 8 * kWave; // 2 KiB
-template <int S>
+template <int S, int CB>
 __host__ __device__ constexpr uint32_t dec_lds_bytes()
 {
   // two element buffers + run starts + run markers + staged sub-chunk
-  return 2 * elem_buf_bytes() + 2 * (kChunkBytes / S) * 2 + kStageWords * 4;
+  return 2 * elem_buf_bytes<CB>() + 2 * (CB / S) * 2 + kStageWords * 4;
 }
 
 // ---- wave reductions (64 lanes) -------------------------------------------
@@ -219,7 +224,7 @@ __device__ __forceinline__ uint32_t chunk_metadata_size(int R, int D)
   return ru((uint32_t)(4 + 4 * (R + 1)), (uint32_t)S) + ru((uint32_t)(S * D), 4u);
 }
 
-template <int S>
+template <int S, int CB>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kernel(
     const uint8_t* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes_arr,
@@ -228,17 +233,17 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
     const int R, const int D, const int bp)
 {
   typedef typename UIntOf<S>::type UT;
-  __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * wave_lds_bytes<S>()];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // kWavesPerBlock * wave_lds_bytes<S, CB>()
   const int lane = lane_id();
   // everything that steers the layers is wave-uniform: say so (see uniform())
   const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
   const size_t part = (size_t)blockIdx.x * kWavesPerBlock + wave;
   if (part >= batch)
     return;
-  uint8_t* my = smem + wave * wave_lds_bytes<S>();
+  uint8_t* my = smem + wave * wave_lds_bytes<S, CB>();
   UT* bufA = reinterpret_cast<UT*>(my);
-  uint16_t* cnts = reinterpret_cast<uint16_t*>(my + elem_buf_bytes());
-  uint32_t* meta = reinterpret_cast<uint32_t*>(my + elem_buf_bytes() + (kChunkBytes / S) * 2);
+  uint16_t* cnts = reinterpret_cast<uint16_t*>(my + elem_buf_bytes<CB>());
+  uint32_t* meta = reinterpret_cast<uint32_t*>(my + elem_buf_bytes<CB>() + (CB / S) * 2);
 
   cgptr in = to_global(uniform_ptr(in_ptrs[part]));
   const size_t in_bytes64 = uniform((uint64_t)in_bytes_arr[part]);
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
   const uint32_t limit = 4u * (2u + (in_bytes + 3u) / 4u); // reference :852-854
   bool use = !(R == 0 && D == 0 && bp == 0);
   uint32_t cur = ru(kPartMeta, S);
-  constexpr uint32_t CE = kChunkBytes / S;
+  constexpr uint32_t CE = CB / S;
   const uint32_t nchunks = (N + CE - 1) / CE;
   const uint32_t msz = chunk_metadata_size<S>(R, D);
   const uint32_t dh_off = ru((uint32_t)(4 + 4 * (R + 1)), (uint32_t)S);
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
     uint32_t n = min(N - c * CE, CE);
     // sub-chunk -> LDS (16 bytes per lane per step; inputs are 4-byte aligned)
     {
-      cgptr src = in + (size_t)c * kChunkBytes;
+      cgptr src = in + (size_t)c * CB;
       const uint32_t nb = n * S;
       uint32_t* dstw = reinterpret_cast<uint32_t*>(bufA);
       for (uint32_t o = (uint32_t)lane * 16u; o < nb; o += kWave * 16u) {
@@ -353,7 +358,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
     total = raw + ru(nb, 4);
   }
   if (lane == 0) {
-    const uint32_t h = use ? ((uint32_t)R | ((uint32_t)D << 8) | ((uint32_t)bp << 16)) : 0u;
+    constexpr uint32_t kCode = CB == 8192 ? 1u : CB == 16384 ? 2u : 0u; // sub-chunk size (see the head of the file)
+    const uint32_t h = use ? ((uint32_t)R | ((uint32_t)D << 8) | (((uint32_t)bp | (kCode << 4)) << 16)) : 0u;
     reinterpret_cast<HC_GLOBAL uint32_t*>(out)[0] = h | ((uint32_t)type_tag << 24);
     reinterpret_cast<HC_GLOBAL uint32_t*>(out)[1] = N * S;
     out_bytes_arr[part] = total;
@@ -437,7 +443,7 @@ __device__ __forceinline__ int wave_read_array(
                           max_elems, lane);
 }
 
-template <int S>
+template <int S, int CB>
 __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
     const uint8_t* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes_arr,
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
     hipcompStatus_t* __restrict__ statuses)
 {
   typedef typename UIntOf<S>::type UT;
-  __shared__ __attribute__((aligned(16))) uint8_t smem[dec_lds_bytes<S>()];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // dec_lds_bytes<S, CB>()
   const int lane = lane_id();
   const size_t part = blockIdx.x;
   if (part >= batch)
@@ -457,12 +463,19 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
   uint32_t type = 0xFFu;
   if (!bad_header)
     type = uniform((uint32_t)comp[3]);
-  // Each width has its own launch; a partition is handled by the launch that
-  // matches ITS type byte (the reference dispatches on partition 0 only).
-  // Undecodable headers are reported by the 1-byte launch.
-  const bool mine = bad_header || type > 7 ? (S == 1) : ((S == 1 && type <= 1) || (S == 2 && (type == 2 || type == 3))
-                                                        || (S == 4 && (type == 4 || type == 5))
-                                                        || (S == 8 && (type == 6 || type == 7)));
+  // Each width and sub-chunk size has its own launch (the LDS a wave needs
+  // depends on both); a partition is handled by the launch that matches ITS
+  // type byte (the reference dispatches on partition 0 only) and ITS sub-chunk
+  // code.  Undecodable headers are reported by the 1-byte 4096 launch.
+  uint32_t code = 0;
+  if (!bad_header)
+    code = uniform((uint32_t)comp[2]) >> 4;
+  const bool undecodable = bad_header || type > 7 || code > 2;
+  constexpr uint32_t kCode = CB == 8192 ? 1u : CB == 16384 ? 2u : 0u;
+  const bool mine = undecodable ? (S == 1 && kCode == 0)
+                                : (code == kCode
+                                   && ((S == 1 && type <= 1) || (S == 2 && (type == 2 || type == 3))
+                                       || (S == 4 && (type == 4 || type == 5)) || (S == 8 && (type == 6 || type == 7))));
   if (!mine)
     return;
   auto finish = [&](bool ok, uint32_t bytes) {
@@ -471,13 +484,13 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
       statuses[part] = ok ? hipcompSuccess : hipcompErrorCannotDecompress;
     }
   };
-  if (bad_header || type > 7) {
+  if (undecodable) {
     finish(false, 0);
     return;
   }
   const uint32_t comp_bytes = (uint32_t)comp_bytes64;
   const uint32_t hdr = uniform(*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp));
-  const int R = (int)(hdr & 0xFFu), D = (int)((hdr >> 8) & 0xFFu), bp = (int)((hdr >> 16) & 0xFFu);
+  const int R = (int)(hdr & 0xFFu), D = (int)((hdr >> 8) & 0xFFu), bp = (int)((hdr >> 16) & 0x0Fu);
   const uint32_t ub = uniform(*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + 4));
   const uint32_t N = ub / S;
   gptr out = to_global(uniform_ptr(out_ptrs[part]));
@@ -501,13 +514,13 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
   }
   uint8_t* my = smem;
   UT* bufA = reinterpret_cast<UT*>(my);
-  UT* bufB = reinterpret_cast<UT*>(my + elem_buf_bytes());
-  uint16_t* cnts = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes());
-  uint16_t* marks = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes() + (kChunkBytes / S) * 2);
-  uint32_t* stage = reinterpret_cast<uint32_t*>(my + 2 * elem_buf_bytes() + 2 * (kChunkBytes / S) * 2);
+  UT* bufB = reinterpret_cast<UT*>(my + elem_buf_bytes<CB>());
+  uint16_t* cnts = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes<CB>());
+  uint16_t* marks = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes<CB>() + (CB / S) * 2);
+  uint32_t* stage = reinterpret_cast<uint32_t*>(my + 2 * elem_buf_bytes<CB>() + 2 * (CB / S) * 2);
   const uint32_t* meta = stage; // the chunk metadata is the head of the staged image
 
-  constexpr uint32_t CE = kChunkBytes / S;
+  constexpr uint32_t CE = CB / S;
   const uint32_t end_w = comp_bytes / 4;
   const uint32_t dh_off = ru((uint32_t)(4 + 4 * (R + 1)), (uint32_t)S);
   const int layers = R > D ? R : D;
@@ -741,48 +754,70 @@ __global__ __launch_bounds__(256) void cascaded_get_sizes_kernel(
 
 } // namespace
 
-void cascaded_launch_compress(
-    const uint8_t* const* in_ptrs, const size_t* in_bytes,
-    uint8_t* const* out_ptrs, size_t* out_bytes, size_t batch, int type_tag,
-    int elem_size, int num_rles, int num_deltas, int use_bp, hipStream_t stream)
+namespace {
+
+typedef void (*CompressKernel)(
+    const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, size_t, int, int, int, int);
+typedef void (*DecompressKernel)(
+    const uint8_t* const*, const size_t*, const size_t*, size_t, uint8_t* const*, size_t*, hipcompStatus_t*);
+
+template <int S>
+CompressKernel compress_kernel_of(uint32_t cb, uint32_t& lds)
 {
-  const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock));
-  const dim3 block(kWave * kWavesPerBlock);
-  switch (elem_size) {
-  case 1:
-    cascaded_compress_kernel<1><<<grid, block, 0, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, batch, type_tag, num_rles, num_deltas, use_bp);
-    break;
-  case 2:
-    cascaded_compress_kernel<2><<<grid, block, 0, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, batch, type_tag, num_rles, num_deltas, use_bp);
-    break;
-  case 4:
-    cascaded_compress_kernel<4><<<grid, block, 0, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, batch, type_tag, num_rles, num_deltas, use_bp);
-    break;
-  default:
-    cascaded_compress_kernel<8><<<grid, block, 0, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, batch, type_tag, num_rles, num_deltas, use_bp);
-    break;
+  switch (cb) {
+  case 8192: lds = kWavesPerBlock * wave_lds_bytes<S, 8192>(); return cascaded_compress_kernel<S, 8192>;
+  case 16384: lds = kWavesPerBlock * wave_lds_bytes<S, 16384>(); return cascaded_compress_kernel<S, 16384>;
+  default: lds = kWavesPerBlock * wave_lds_bytes<S, 4096>(); return cascaded_compress_kernel<S, 4096>;
   }
 }
 
+template <int S, int CB>
+void launch_decompress(
+    const uint8_t* const* comp_ptrs, const size_t* comp_bytes, const size_t* out_caps, size_t batch,
+    uint8_t* const* out_ptrs, size_t* actual_bytes, hipcompStatus_t* statuses, hipStream_t stream)
+{
+  DecompressKernel k = cascaded_decompress_kernel<S, CB>;
+  constexpr uint32_t lds = dec_lds_bytes<S, CB>();
+  if (lds > 64 * 1024) { // has to be asked for (idempotent, cheap)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        != hipSuccess)
+      return;
+  }
+  k<<<dim3((unsigned)batch), dim3(kWave), lds, stream>>>(comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes,
+                                                         statuses);
+}
+
+} // namespace
+
+// chunk_bytes: 4096, 8192 or 16384 (the caller maps every other value to 4096)
+void cascaded_launch_compress(
+    const uint8_t* const* in_ptrs, const size_t* in_bytes,
+    uint8_t* const* out_ptrs, size_t* out_bytes, size_t batch, int type_tag,
+    int elem_size, int num_rles, int num_deltas, int use_bp, uint32_t chunk_bytes, hipStream_t stream)
+{
+  const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock));
+  const dim3 block(kWave * kWavesPerBlock);
+  uint32_t lds = 0;
+  CompressKernel k = elem_size == 1   ? compress_kernel_of<1>(chunk_bytes, lds)
+                     : elem_size == 2 ? compress_kernel_of<2>(chunk_bytes, lds)
+                     : elem_size == 4 ? compress_kernel_of<4>(chunk_bytes, lds)
+                                      : compress_kernel_of<8>(chunk_bytes, lds);
+  k<<<grid, block, lds, stream>>>(in_ptrs, in_bytes, out_ptrs, out_bytes, batch, type_tag, num_rles, num_deltas, use_bp);
+}
+
+// One launch per element width and sub-chunk size (the reference: one per
+// width); a launch leaves the partitions of the others alone.  The common
+// ones first.
 void cascaded_launch_decompress(
     const uint8_t* const* comp_ptrs, const size_t* comp_bytes,
     const size_t* out_caps, size_t batch, uint8_t* const* out_ptrs,
     size_t* actual_bytes, hipcompStatus_t* statuses, hipStream_t stream)
 {
-  const dim3 grid((unsigned)batch);
-  const dim3 block(kWave);
-  cascaded_decompress_kernel<4><<<grid, block, 0, stream>>>(
-      comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
-  cascaded_decompress_kernel<8><<<grid, block, 0, stream>>>(
-      comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
-  cascaded_decompress_kernel<2><<<grid, block, 0, stream>>>(
-      comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
-  cascaded_decompress_kernel<1><<<grid, block, 0, stream>>>(
-      comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
+#define HC_DEC(S, CB) launch_decompress<S, CB>(comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses, stream)
+  HC_DEC(4, 4096); HC_DEC(8, 4096); HC_DEC(2, 4096); HC_DEC(1, 4096);
+  HC_DEC(4, 8192); HC_DEC(8, 8192); HC_DEC(2, 8192); HC_DEC(1, 8192);
+  HC_DEC(4, 16384); HC_DEC(8, 16384); HC_DEC(2, 16384); HC_DEC(1, 16384);
+#undef HC_DEC
 }
 
 void cascaded_launch_get_sizes(

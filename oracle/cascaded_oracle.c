@@ -43,8 +43,17 @@
 #include <stdint.h>
 #include <string.h>
 
-#define CHUNK_BYTES 4096
+#define CHUNK_BYTES 4096      /* the reference's (hard-wired) sub-chunk, CascadedKernels.hiph:88 */
+#define MAX_CHUNK_BYTES 16384 /* this library honours opts.chunk_size 8192 and 16384 as well */
 #define PART_META 8
+
+/* Sub-chunk sizes other than the reference's are an extension of the format:
+ * the high nibble of header byte 2 (use_bp, 0 or 1 in the reference) says
+ * which -- 0: 4096 (every reference stream), 1: 8192, 2: 16384. */
+static int chunk_code_of(size_t chunk_bytes)
+{
+  return chunk_bytes == 8192 ? 1 : chunk_bytes == 16384 ? 2 : 0;
+}
 
 static size_t ru(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
@@ -171,11 +180,13 @@ static size_t write_array(
  * s its size in bytes.  out/mask must hold oracle_cascaded_max_compressed_size
  * (in_bytes) bytes (and are fully initialised: untouched bytes get mask 0).
  */
-int oracle_cascaded_compress(
-    const uint8_t* in, size_t in_bytes, int type, int s, int R, int D, int bp,
+int oracle_cascaded_compress_cb(
+    const uint8_t* in, size_t in_bytes, int type, int s, int R, int D, int bp, size_t chunk_bytes,
     uint8_t* out, uint8_t* mask, size_t* out_bytes)
 {
-  static __thread uint64_t a[CHUNK_BYTES], b[CHUNK_BYTES], cnt[CHUNK_BYTES]; /* per thread: bench_codecs.py times this from a thread pool */
+  static __thread uint64_t a[MAX_CHUNK_BYTES], b[MAX_CHUNK_BYTES], cnt[MAX_CHUNK_BYTES]; /* per thread: timed from a thread pool */
+  const int code = chunk_code_of(chunk_bytes);
+  const size_t cb = code == 1 ? 8192 : code == 2 ? 16384 : CHUNK_BYTES; /* anything else: the reference's */
   const size_t cap = oracle_cascaded_max_compressed_size(in_bytes);
   memset(out, 0, cap);
   memset(mask, 0, cap);
@@ -189,7 +200,7 @@ int oracle_cascaded_compress(
   const size_t limit = 4 * (2 + (in_bytes + 3) / 4);     /* :852-854, bytes */
   int use = !(R == 0 && D == 0 && bp == 0);              /* :868-870 */
   size_t cur = ru(PART_META, (size_t)s);                 /* :873-876 */
-  const size_t ce = CHUNK_BYTES / (size_t)s;
+  const size_t ce = cb / (size_t)s;
   const size_t nchunks = (N + ce - 1) / ce;
   const int msz = chunk_metadata_size(s, R, D);
   const size_t dh_off = ru((size_t)(4 + 4 * (R + 1)), (size_t)s);
@@ -259,7 +270,7 @@ int oracle_cascaded_compress(
 
   uint8_t hdr[8];
   if (use) {
-    hdr[0] = (uint8_t)R; hdr[1] = (uint8_t)D; hdr[2] = (uint8_t)bp;
+    hdr[0] = (uint8_t)R; hdr[1] = (uint8_t)D; hdr[2] = (uint8_t)((bp ? 1 : 0) | (code << 4));
     *out_bytes = cur;
   } else {                                               /* :1019-1053 */
     memset(out, 0, cap);
@@ -274,6 +285,13 @@ int oracle_cascaded_compress(
   memcpy(hdr + 4, &ub, 4);
   put(&k, 0, hdr, 8, 1);
   return 0;
+}
+
+int oracle_cascaded_compress(
+    const uint8_t* in, size_t in_bytes, int type, int s, int R, int D, int bp,
+    uint8_t* out, uint8_t* mask, size_t* out_bytes)
+{
+  return oracle_cascaded_compress_cb(in, in_bytes, type, s, R, D, bp, CHUNK_BYTES, out, mask, out_bytes);
 }
 
 /* get_decompress_size_kernel, CascadedBatch.hip:262-281 */
@@ -332,12 +350,15 @@ static long read_array(
 int oracle_cascaded_decompress(
     const uint8_t* comp, size_t comp_bytes, uint8_t* out, size_t cap, size_t* actual)
 {
-  static __thread uint64_t a[CHUNK_BYTES], b[CHUNK_BYTES], cnt[CHUNK_BYTES]; /* per thread: bench_codecs.py times this from a thread pool */
+  static __thread uint64_t a[MAX_CHUNK_BYTES], b[MAX_CHUNK_BYTES], cnt[MAX_CHUNK_BYTES]; /* per thread: timed from a thread pool */
   static const int sizes[8] = {1, 1, 2, 2, 4, 4, 8, 8};
   *actual = 0;
   if (comp_bytes < PART_META)
     return 12;
-  const int R = comp[0], D = comp[1], bp = comp[2], type = comp[3];
+  const int R = comp[0], D = comp[1], bp = comp[2] & 0x0F, type = comp[3];
+  const int code = comp[2] >> 4;                         /* sub-chunk size (see chunk_code_of) */
+  if (code > 2) return 12;
+  const size_t cb = code == 1 ? 8192 : code == 2 ? 16384 : CHUNK_BYTES;
   if (type > 7) return 12;
   const int s = sizes[type];
   uint32_t ub;
@@ -357,7 +378,7 @@ int oracle_cascaded_decompress(
   const size_t end_w = comp_bytes / 4;                   /* partition_end_ptr */
   const int msz = chunk_metadata_size(s, R, D);
   const size_t dh_off = ru((size_t)(4 + 4 * (R + 1)), (size_t)s);
-  const size_t ce = CHUNK_BYTES / (size_t)s;
+  const size_t ce = cb / (size_t)s;
   size_t pos = ru(PART_META, (size_t)s), done = 0;
   int ok = 1;
   while (pos / 4 < end_w) {                              /* :1268 */

@@ -145,3 +145,43 @@ def test_large_partitions(hc, oracle, reflib, cuda):
         dec, actual, statuses = codec.decompress(mine, len(c) + 16)
         assert statuses.cpu().tolist() == [0]
         assert dec.to_host_chunks()[0] == c[: len(c) // s * s]
+
+
+@pytest.mark.parametrize("cb", [8192, 16384])
+def test_chunk_size_option_is_honoured(hc, oracle, cuda, cb):
+    """hipcompBatchedCascadedOpts_t.chunk_size 8192 / 16384: kernel == oracle
+    byte for byte, round trips, and partitions of all three sub-chunk sizes and several types
+    decode side by side in one batch."""
+    import torch
+    for R, D, bp in ((2, 1, 1), (1, 0, 0), (0, 2, 1)):
+        mixed, expect = [], []
+        for t in range(8):
+            chunks = _inputs(t, oracle)
+            src = hc.batch.from_host_chunks(chunks, "cuda:0")
+            codec = hc.batch.Codec("Cascaded", hc.CascadedOpts(cb, t, R, D, bp))
+            mine = codec.compress(src)
+            torch.cuda.synchronize()
+            got = mine.to_host_chunks()
+            s = oracle.CASCADED_TYPE_SIZE[t]
+            for i, c in enumerate(chunks):
+                want, _ = oracle.cascaded_compress(c, t, R, D, bp, cb)
+                assert got[i] == want, f"type {t} opts {(R, D, bp)} chunk_size {cb} input {i}: kernel != oracle"
+            dec, actual, statuses = codec.decompress(mine, 65536 * 2)
+            for i, c in enumerate(chunks):
+                if len(c):
+                    e = c[: len(c) // s * s]
+                    assert statuses[i].item() == 0 and dec.chunk_bytes(i, int(actual[i].item())) == e
+            mixed += [got[0], oracle.cascaded_compress(chunks[1], t, R, D, bp)[0],
+                      oracle.cascaded_compress(chunks[0], t, R, D, bp, 24576 - cb)[0]]
+            expect += [chunks[0][: len(chunks[0]) // s * s], chunks[1][: len(chunks[1]) // s * s],
+                       chunks[0][: len(chunks[0]) // s * s]]
+        comp = hc.batch.from_host_chunks(mixed, "cuda:0")
+        dec, actual, statuses = hc.batch.Codec("Cascaded").decompress(comp, 65536 * 2)
+        assert statuses.cpu().tolist() == [0] * len(mixed)
+        for i, e in enumerate(expect):
+            assert dec.chunk_bytes(i, int(actual[i].item())) == e
+    # any other chunk_size means the reference's 4096
+    src = hc.batch.from_host_chunks([_sorted_column(1, 16384).tobytes()], "cuda:0")
+    a = hc.batch.Codec("Cascaded", hc.CascadedOpts(4096, 5, 2, 1, 1)).compress(src).to_host_chunks()
+    b = hc.batch.Codec("Cascaded", hc.CascadedOpts(12345, 5, 2, 1, 1)).compress(src).to_host_chunks()
+    assert a == b

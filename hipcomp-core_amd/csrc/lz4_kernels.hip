@@ -558,14 +558,9 @@ __device__ __forceinline__ void agpr_load_u32(cgptr base, uint32_t byte_off)
 }
 
 // waits until at most N younger loads are in flight, then a[A0 .. A0+3] -> r
-template <int A0, int N_>
+template <int A0, int N>
 __device__ __forceinline__ void agpr_take4(uint32_t (&r)[4])
 {
-#ifdef HC_ABL_NOWAIT // measurement builds only (wrong output): 1 = no wait for candidate words, 2 = none for window words, 3 = neither
-  constexpr int N = ((HC_ABL_NOWAIT & 1) && A0 >= 12) || ((HC_ABL_NOWAIT & 2) && A0 < 12) ? 63 : N_;
-#else
-  constexpr int N = N_;
-#endif
   asm volatile("s_waitcnt vmcnt(%4)\n\t"
                "v_accvgpr_read_b32 %0, a[%5]\n\t"
                "v_accvgpr_read_b32 %1, a[%6]\n\t"

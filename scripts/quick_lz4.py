@@ -15,6 +15,7 @@ ap.add_argument("--check", action="store_true")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--lib", default=None, help="another build of the library (measurement variants)")
 ap.add_argument("--no-verify", action="store_true")
+ap.add_argument("--count-sequences", action="store_true", help="LZ4 sequences per chunk (mean of the first 64 chunks)")
 a = ap.parse_args()
 hc = importlib.import_module("hipcomp-core_amd")
 dev = torch.device("cuda:0")
@@ -48,6 +49,30 @@ for dist in a.dist.split(","):
                     same = bool(((A == B) | ~idx).all().item())
                 line += f" | same_as_reference={same}"
                 del rjob
+        if a.count_sequences:
+            def sequences(blk: bytes) -> int:
+                i, n = 0, 0
+                while i < len(blk):
+                    tok = blk[i]; i += 1
+                    lit = tok >> 4
+                    if lit == 15:
+                        while True:
+                            b = blk[i]; i += 1; lit += b
+                            if b != 255: break
+                    i += lit
+                    n += 1
+                    if i >= len(blk): break
+                    i += 2
+                    if (tok & 15) == 15:
+                        while True:
+                            b = blk[i]; i += 1
+                            if b != 255: break
+                return n
+            k = min(64, job.n)
+            sizes = job.comp.sizes[:k].cpu().tolist()
+            host = job.comp.data[: k * job.comp.stride].cpu().numpy()
+            tot = sum(sequences(host[i * job.comp.stride: i * job.comp.stride + sizes[i]].tobytes()) for i in range(k))
+            line += f" | sequences_per_chunk={tot / k:.1f}"
         print(line, flush=True)
         del job, data
         torch.cuda.empty_cache()

@@ -227,9 +227,11 @@ struct LZ4Manager::Impl
   bool own_scratch = false;
   CommonHeader* header_host = nullptr; // pinned
 
-  // scratch: chunk lists of a slab, three words for the compress kernels, the slots
+  // scratch: chunk lists of a slab, three words for the compress kernels, the
+  // slots, hash tables for the compress kernel's "far" shape (one per chunk of a slab)
   size_t lists_bytes() const { return (size_t)slab * (8 + 8 + 8 + 8 + 8 + 4) + 64; }
-  size_t scratch_bytes() const { return lists_bytes() + (size_t)slab * slot_bytes; }
+  size_t table_bytes() const { return (size_t)(ht_size < 8 ? 8 : ht_size) * sizeof(uint16_t); }
+  size_t scratch_bytes() const { return lists_bytes() + (size_t)slab * slot_bytes + 16 + (size_t)slab * table_bytes(); }
   uint8_t* ensure_scratch()
   {
     if (!scratch) {
@@ -301,6 +303,8 @@ void LZ4Manager::compress(const uint8_t* decomp_buffer, uint8_t* comp_buffer, co
   uint8_t** out_ptrs = reinterpret_cast<uint8_t**>(s + (size_t)m.slab * 16);
   uint32_t* words = reinterpret_cast<uint32_t*>(s + (size_t)m.slab * 44);
   uint8_t* slots = s + m.lists_bytes();
+  uint16_t* tables = reinterpret_cast<uint16_t*>(
+      (reinterpret_cast<uintptr_t>(slots + (size_t)m.slab * m.slot_bytes) + 15) & ~uintptr_t(15));
   header_kernel<<<1, 1, 0, m.stream>>>(comp_buffer, cfg.uncompressed_buffer_size, n, m.chunk_bytes, (uint32_t)lay.data,
                                        (uint32_t)m.data_type, cfg.get_status());
   for (size_t first = 0; first < n; first += m.slab) {
@@ -310,7 +314,8 @@ void LZ4Manager::compress(const uint8_t* decomp_buffer, uint8_t* comp_buffer, co
         in_bytes, out_ptrs);
     // sizes go straight into the container's size array
     check(lz4_launch_compress(in_ptrs, in_bytes, out_ptrs, reinterpret_cast<size_t*>(comp_buffer + lay.sizes) + first,
-                              m.ht_size, count, m.elem, words, m.chunk_bytes, lz4_mode_from_environment(), m.stream),
+                              m.ht_size, count, m.elem, words, tables, m.slab, m.chunk_bytes, lz4_mode_from_environment(),
+                              m.stream),
           "LZ4Manager::compress");
     slab_place_kernel<<<1, kBlock, 0, m.stream>>>(comp_buffer, lay.sizes, lay.offsets, first, count);
     slab_gather_kernel<<<(count + 3) / 4, kBlock, 0, m.stream>>>(comp_buffer, lay.sizes, lay.offsets, lay.data, first,

@@ -368,9 +368,11 @@ __device__ __forceinline__ uint32_t window_winner(const Window& W, int lane)
   return W.valid ? W.w_raw : (uint32_t)lane;
 }
 
+// First lane with an equal lower lane (nv if none) and that lower lane.
 // nw = word of window_winner's lane (one ds_bpermute, issued by the caller).
 template <int NVMAX>
-__device__ __forceinline__ Decision window_decide(const Window& W, uint32_t nw, int lane)
+__device__ __forceinline__ void window_first_duplicate(
+    const Window& W, uint32_t nw, int lane, int& f, uint32_t& mlane)
 {
   const uint64_t vmask = lanes_below<NVMAX>(W.nv);
   const uint32_t w = window_winner(W, lane);
@@ -379,9 +381,8 @@ __device__ __forceinline__ Decision window_decide(const Window& W, uint32_t nw, 
   const uint64_t dupmask = eqmask & wave_ballot(w != (uint32_t)lane);
   const uint64_t unres = vmask & ~eqmask;
 
-  // first lane with an equal lower lane (nv if none) and that lower lane
-  int f = dupmask ? __builtin_ctzll(dupmask) : W.nv;
-  uint32_t mlane = read_lane(w, f & 63);
+  f = dupmask ? __builtin_ctzll(dupmask) : W.nv;
+  mlane = read_lane(w, f & 63);
   uint64_t U = unres & lanes_below<NVMAX>(f);
   if (__builtin_expect(U != 0, 0)) {
     do {
@@ -397,10 +398,19 @@ __device__ __forceinline__ Decision window_decide(const Window& W, uint32_t nw, 
       }
     } while (U);
   }
-  // earliest lane (< f) with a verified table candidate wins
-  // (reference :896-923)
-  const uint64_t tmask
-      = wave_ballot(W.cand_word == W.word) & W.probe & lanes_below<NVMAX>(f);
+}
+
+// Lanes below f whose table candidate holds the lane's word.
+template <int NVMAX>
+__device__ __forceinline__ uint64_t window_table_matches(const Window& W, int f)
+{
+  return wave_ballot(W.cand_word == W.word) & W.probe & lanes_below<NVMAX>(f);
+}
+
+// The earliest lane with a verified table candidate wins over the first
+// in-window duplicate at f (reference :896-923).
+__device__ __forceinline__ Decision window_settle(const Window& W, int f, uint32_t mlane, uint64_t tmask)
+{
   const bool in_window = f < W.nv;
   if (tmask)
     f = __builtin_ctzll(tmask);
@@ -410,6 +420,15 @@ __device__ __forceinline__ Decision window_decide(const Window& W, uint32_t nw, 
   D.f = f;
   D.match_location = tmask ? tcand : W.d + mlane; // reference :925-956
   return D;
+}
+
+template <int NVMAX>
+__device__ __forceinline__ Decision window_decide(const Window& W, uint32_t nw, int lane)
+{
+  int f;
+  uint32_t mlane;
+  window_first_duplicate<NVMAX>(W, nw, lane, f, mlane);
+  return window_settle(W, f, mlane, window_table_matches<NVMAX>(W, f));
 }
 
 // Table state "only the first f lanes of W were inserted", from the state in
@@ -1123,26 +1142,29 @@ __device__ __forceinline__ void compress_wave(
  } // next ticket
 }
 
-// Workgroup shapes.  A chunk's tables (ht_size x u16, + ht_size x u8 of tags;
-// 32 / 48 KiB for 64 KiB chunks) are the only LDS user and LDS is what limits
-// residency; the CU hands LDS out in 1280-byte granules, so ONE workgroup that
-// owns all 160 KiB holds more tables than several small ones.  Each wave owns
-// one set of tables and takes chunks from a global ticket counter until the
-// batch is exhausted; the waves never synchronise with each other.
-//   "mix"   up to four waves, the first n_tagged of them with a tag table
-//           (64 KiB chunks: two with, two without = 160 KiB to the byte), all
-//           with the walk: the shape for data with match-less stretches;
-//   "flat"  five waves, no tags, no walk (128 vector registers): the most
-//           chunks in flight, for data that has a match in nearly every window.
+// Workgroup shapes.  Each wave owns one set of tables and takes chunks from a
+// global ticket counter until the batch is exhausted; the waves never
+// synchronise with each other.
+//   "mix"   tables in LDS.  They (ht_size x u16, + ht_size x u8 of tags; 32 /
+//           48 KiB for 64 KiB chunks) are the only LDS user and LDS is what
+//           limits residency; the CU hands LDS out in 1280-byte granules, so
+//           ONE workgroup that owns all 160 KiB holds more tables than several
+//           small ones.  Up to four waves, the first n_tagged of them with a
+//           tag table (64 KiB chunks: two with, two without = 160 KiB to the
+//           byte), all with the walk: the shape for data with match-less
+//           stretches, and for batches small enough to be in flight at once.
+//   "far"   tables in device memory, 32 waves per CU, no tags, no walk (64
+//           vector registers): for data that has a match in nearly every
+//           window (compress_wave_far below).
 // `mode` (may be null) points at the two counters of the sampling kernel: a
 // kernel whose shape is not the one they call for leaves at once.
-constexpr uint32_t kModeMix = 1, kModeFlat = 2;
+constexpr uint32_t kModeMix = 1, kModeFar = 2;
 
 // {words that repeated, words looked at} -> shape
 __device__ __forceinline__ uint32_t sampled_mode(const uint32_t* counters)
 {
   const uint32_t repeats = uniform(counters[0]), looked = uniform(counters[1]);
-  return (looked != 0 && repeats * 4u > looked) ? kModeFlat : kModeMix;
+  return (looked != 0 && repeats * 4u > looked) ? kModeFar : kModeMix;
 }
 
 template <int S>
@@ -1166,20 +1188,226 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
                                   ticket, chunks_per_ticket);
 }
 
+// ---------------------------------------------------------------------------
+// The "far" shape: the position table of a chunk lies in device memory (a
+// slice of the caller's temp buffer, where the reference keeps it), so that
+// LDS no longer limits how many chunks a CU works on -- sixteen waves instead
+// of five.  For data with a match in nearly every window the encoder is a
+// chain of dependent round trips per sequence and only more chains in flight
+// make it faster; a table round trip that is several times longer is the
+// lesser evil.  One window at a time, no tags, no walk.
+//
+// What LDS did for the tables is done as follows.
+//   in-window duplicates: lane ids posted in reversed lane order as in
+//     window_markers, but into a small per-wave LDS scratch indexed by the low
+//     bits of the slot number.  Lanes of one table slot share a scratch slot,
+//     so a lane whose scratch slot names a lane with ITS word has found the
+//     lowest lane holding that word; any other lane is settled by the exact
+//     fallback of window_decide.
+//   insert rule: the same store masks as insert_sigma / the n <= 31 rule, but
+//     of the lanes of a mask that share a table slot only the one LDS would
+//     have kept stores (slot_tops) -- no same-address stores, so nothing
+//     depends on how global memory would arbitrate them.
+// A wave's loads from its table see its earlier stores: same wave, same
+// address, program order.
+// ---------------------------------------------------------------------------
+constexpr int kFarWavesPerGroup = 4;
+constexpr int kFarFirst = 8; // lanes whose table slots are looked up before the rest
+constexpr int kFarGroupsPerCu = 8; // 32 waves: 64 vector registers each
+constexpr uint32_t kFarScratchSlots = 2048; // u16 each, per wave: 128 KiB per CU
+
+// Of the lanes of `range`, those that are the highest lane of their table slot
+// among the lanes of `range`.
+__device__ __forceinline__ uint64_t slot_tops(
+    uint32_t hpos, uint64_t range, uint16_t* scr, int lane)
+{
+  uint64_t tops = 0;
+  if (__builtin_popcountll(range) <= 6) {
+    uint64_t rem = range;
+    while (rem) {
+      const int u = 63 - __builtin_clzll(rem);
+      tops |= 1ull << u;
+      rem &= ~wave_ballot(hpos == read_lane(hpos, u));
+    }
+    return tops;
+  }
+  // lane ids into the scratch in natural lane order: the highest lane of a
+  // scratch slot stays
+  const uint32_t ks = hpos & (kFarScratchSlots - 1u);
+  const bool in = (range >> lane) & 1ull;
+  lds_lane_exchange_fence();
+  if (in)
+    scr[ks] = (uint16_t)lane;
+  lds_lane_exchange_fence();
+  const uint32_t top = in ? (uint32_t)scr[ks] : (uint32_t)lane;
+  lds_lane_exchange_fence();
+  const uint32_t htop = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(top * 4u), (int)hpos);
+  // top == lane: highest lane of my scratch slot, hence of my table slot;
+  // htop == hpos: a higher lane of my table slot;  else a lane of another
+  // table slot hides mine: exact compare
+  tops = wave_ballot(top == (uint32_t)lane) & range;
+  uint64_t U = range & ~tops & ~wave_ballot(htop == hpos);
+  while (__builtin_expect(U != 0, 0)) {
+    const int u = __builtin_ctzll(U);
+    U &= U - 1;
+    const uint64_t m = wave_ballot(hpos == read_lane(hpos, u)) & range;
+    if (63 - __builtin_clzll(m) == u)
+      tops |= 1ull << u;
+  }
+  return tops;
+}
+
+// table[hpos] = value for the lanes of `mask` (distinct slots)
+__device__ __forceinline__ void far_store_masked(
+    HC_GLOBAL uint16_t* table, uint32_t hpos, uint32_t value, uint64_t mask, int lane)
+{
+  if ((mask >> lane) & 1ull)
+    table[hpos] = (uint16_t)value;
+}
+
+// Table state "the first n lanes of W were inserted" (see insert_sigma for the rule).
+template <int NVMAX>
+__device__ __forceinline__ void far_insert_first(
+    const Window& W, HC_GLOBAL uint16_t* table, uint16_t* scr, int n, int perm_addr4, uint32_t sig,
+    uint32_t hmask, int lane)
+{
+  if (n >= 32) {
+    const uint32_t ws = (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr4, (int)W.word);
+    const uint32_t hp = hash_sum(ws) & hmask;
+    uint64_t in31;
+    const uint64_t store = sigma_store_mask(hp, wave_ballot(sig < (uint32_t)n), n == 64, in31);
+    far_store_masked(table, hp, (W.d + sig) & 0xFFFFu, slot_tops(hp, store, scr, lane), lane);
+  } else if (n > 0) {
+    far_store_masked(table, W.hpos, (W.d + (uint32_t)lane) & 0xFFFFu,
+                     slot_tops(W.hpos, lanes_below<NVMAX>(n), scr, lane), lane);
+  }
+}
+
 template <int S>
-__global__ __launch_bounds__(kLz4FlatWavesPerGroup * kWave) void lz4_compress_kernel_flat(
+__device__ __forceinline__ void compress_wave_far(
+    const uint8_t* const* __restrict__ in_ptrs,
+    const size_t* __restrict__ in_bytes,
+    uint8_t* const* __restrict__ out_ptrs,
+    size_t* __restrict__ out_bytes,
+    const uint32_t ht_size,
+    HC_GLOBAL uint16_t* const table,
+    uint16_t* const scr,
+    const uint32_t batch,
+    uint32_t* __restrict__ ticket,
+    const uint32_t chunks_per_ticket)
+{
+  constexpr uint32_t LVM = (12 + S - 1) / S;
+  constexpr int NVMAX = kWave - 3 / S;
+  const int lane = lane_id();
+  const uint32_t hmask = ht_size - 1;
+  const uint32_t sig = sigma_of_lane(lane);
+  const int perm_addr4 = (int)(sig * 4u);
+  const uint32_t rev_lane = 63u - (uint32_t)lane;
+  const int rev_addr4 = (int)(rev_lane * 4u);
+  Tables<false> no_tags; // (window_candidate asks it whether tags filter: never)
+  no_tags.filter = false;
+
+  for (;;) {
+    const uint32_t first = take_ticket(ticket, chunks_per_ticket);
+    if (first >= batch)
+      break;
+    const uint32_t stop = min(first + chunks_per_ticket, batch);
+    for (uint32_t chunk = first; chunk < stop; ++chunk) {
+      cgptr __restrict__ in = to_global(in_ptrs[chunk]);
+      const uint32_t len = (uint32_t)in_bytes[chunk];
+      gptr __restrict__ out = to_global(out_ptrs[chunk]);
+      const uint32_t L = (len + S - 1) / S;
+      {
+        u32x4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        HC_GLOBAL u32x4* p = reinterpret_cast<HC_GLOBAL u32x4*>(table);
+        const uint32_t nvec = ((ht_size * 2 + 15) & ~15u) >> 4;
+        for (uint32_t i = (uint32_t)lane; i < nvec; i += kWave)
+          p[i] = ones;
+      }
+      uint32_t d = 0, c = 0;
+      const uint32_t last_word = L > LVM ? L - LVM - 1 : 0;
+      uint32_t next = 0;
+      if (L > LVM)
+        next = load_u32_any(in + (size_t)min((uint32_t)lane, last_word) * S);
+      int cold = 0;
+      uint32_t token_start = 0;
+      while (d < L) {
+        if (d + LVM >= L) {
+          c = write_sequence(out, c, in + (size_t)token_start * S, len - token_start * S, 0, 0, lane);
+          break;
+        }
+        Window P;
+        window_begin<S, NVMAX>(P, d, next, L, hmask, lane);
+        // Table slots of the first kFarFirst lanes only: that is where the match
+        // of a window of compressible data is, and a slot costs a memory
+        // transaction.  (In flight while the duplicates are looked for.)
+        P.h_old = kNullOffset;
+        if (lane < kFarFirst)
+          P.h_old = table[P.hpos];
+        P.t_old = 0;
+        const uint32_t ks = P.hpos & (kFarScratchSlots - 1u);
+        const uint32_t pr = (uint32_t)__builtin_amdgcn_ds_bpermute(
+            rev_addr4, (int)(ks | (P.valid ? 0x80000000u : 0u)));
+        lds_lane_exchange_fence();
+        if (pr & 0x80000000u)
+          scr[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
+        lds_lane_exchange_fence();
+        P.w_raw = scr[ks];
+        lds_lane_exchange_fence();
+        const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
+            (int)(window_winner(P, lane) * 4u), (int)P.word);
+        int f;
+        uint32_t mlane;
+        window_first_duplicate<NVMAX>(P, nw, lane, f, mlane);
+        window_candidate<S>(P, no_tags, in, last_word, lane, cold > 0);
+        uint64_t tmask = window_table_matches<NVMAX>(P, f);
+        if (tmask == 0 && f > kFarFirst) {
+          // no match among the first lanes: the slots of the lanes up to f
+          P.h_old = kNullOffset;
+          if (lane >= kFarFirst && lane < f)
+            P.h_old = table[P.hpos];
+          window_candidate<S>(P, no_tags, in, last_word, lane, false);
+          tmask = window_table_matches<NVMAX>(P, f);
+        }
+        const Decision D = window_settle(P, f, mlane, tmask);
+        if (D.match) {
+          far_insert_first<NVMAX>(P, table, scr, D.f, perm_addr4, sig, hmask, lane);
+          emit_match<S>(out, c, in, token_start, P.d, P.word, D, L, lane, d);
+          next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+          token_start = d;
+          cold = 0;
+        } else {
+          far_insert_first<NVMAX>(P, table, scr, P.nv, perm_addr4, sig, hmask, lane);
+          d += (uint32_t)P.nv;
+          next = cold > 0 ? P.next_word
+                          : load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+          ++cold;
+        }
+      }
+      if (lane == 0)
+        out_bytes[chunk] = c;
+    }
+  }
+}
+
+// tables = far_waves x max(ht_size, 8) x u16 in device memory, 16-byte aligned
+template <int S>
+__global__ __launch_bounds__(kFarWavesPerGroup * kWave, kFarGroupsPerCu) void lz4_compress_kernel_far(
     const uint8_t* const* __restrict__ in_ptrs, const size_t* __restrict__ in_bytes,
     uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ out_bytes,
-    const uint32_t ht_size, const uint32_t stride_plain,
+    const uint32_t ht_size, uint16_t* __restrict__ tables,
     const uint32_t batch, uint32_t* __restrict__ ticket, const uint32_t chunks_per_ticket,
     const uint32_t* __restrict__ mode)
 {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  if (mode && sampled_mode(mode) != kModeFlat)
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // kFarScratchSlots x u16 per wave
+  if (mode && sampled_mode(mode) != kModeFar)
     return;
   const uint32_t wave = uniform((uint32_t)(threadIdx.x >> 6));
-  compress_wave<S, false, false>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, smem + wave * stride_plain, wave,
-                                 batch, ticket, chunks_per_ticket);
+  const size_t gw = (size_t)blockIdx.x * kFarWavesPerGroup + wave;
+  compress_wave_far<S>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size,
+                       (HC_GLOBAL uint16_t*)(tables + gw * max(ht_size, 8u)), // (16 bytes at least: filled 16 at a time)
+                       reinterpret_cast<uint16_t*>(smem) + wave * kFarScratchSlots, batch, ticket,
+                       chunks_per_ticket);
 }
 
 // Which shape suits the data: kSampleChunks chunks spread over the batch (one
@@ -1482,19 +1710,18 @@ int num_cus_of_current_device()
 typedef void (*MixKernel)(
     const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t, uint32_t,
     uint32_t, uint32_t*, uint32_t, const uint32_t*);
-typedef void (*FlatKernel)(
-    const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t, uint32_t*,
-    uint32_t, const uint32_t*);
+typedef void (*FarKernel)(const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint16_t*,
+                          uint32_t, uint32_t*, uint32_t, const uint32_t*);
 
 MixKernel mix_kernel_for(int elem_size)
 {
   return elem_size == 1 ? lz4_compress_kernel_mix<1> : elem_size == 2 ? lz4_compress_kernel_mix<2>
                                                                       : lz4_compress_kernel_mix<4>;
 }
-FlatKernel flat_kernel_for(int elem_size)
+FarKernel far_kernel_for(int elem_size)
 {
-  return elem_size == 1 ? lz4_compress_kernel_flat<1> : elem_size == 2 ? lz4_compress_kernel_flat<2>
-                                                                       : lz4_compress_kernel_flat<4>;
+  return elem_size == 1 ? lz4_compress_kernel_far<1> : elem_size == 2 ? lz4_compress_kernel_far<2>
+                                                                      : lz4_compress_kernel_far<4>;
 }
 
 // more than 64 KiB of dynamic LDS has to be asked for, once per kernel and device
@@ -1512,9 +1739,6 @@ hipError_t raise_dynamic_lds_limit()
   for (int es = 1; es <= 4 && r == hipSuccess; es *= 2) {
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(mix_kernel_for(es)),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (r == hipSuccess)
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_kernel_for(es)),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   g_lds_raised[dev].store(r == hipSuccess ? 1 : -(int)r, std::memory_order_release);
   return r;
@@ -1579,31 +1803,14 @@ Lz4CompressShape lz4_compress_shape_mix(uint32_t ht_size, size_t batch)
   return sh;
 }
 
-Lz4CompressShape lz4_compress_shape_flat(uint32_t ht_size, size_t batch)
-{
-  Lz4CompressShape sh;
-  sh.stride_tagged = 0;
-  sh.stride_plain = round_up(ht_size * 2u, 16u);
-  sh.tagged = 0;
-  uint32_t w = kLdsPerCu / sh.stride_plain;
-  if (w > (uint32_t)kLz4FlatWavesPerGroup)
-    w = kLz4FlatWavesPerGroup;
-  if ((size_t)w > batch)
-    w = (uint32_t)batch;
-  sh.plain = w;
-  sh.lds_bytes = w * sh.stride_plain;
-  set_groups(sh, batch);
-  return sh;
-}
-
 Lz4Mode lz4_mode_from_environment()
 {
   static const Lz4Mode mode = [] {
     const char* e = std::getenv("HIPCOMP_LZ4_SHAPE");
     if (e && std::strcmp(e, "mix") == 0)
       return Lz4Mode::Mix;
-    if (e && std::strcmp(e, "flat") == 0)
-      return Lz4Mode::Flat;
+    if (e && std::strcmp(e, "far") == 0)
+      return Lz4Mode::Far;
     return Lz4Mode::Auto;
   }();
   return mode;
@@ -1612,17 +1819,24 @@ Lz4Mode lz4_mode_from_environment()
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, uint32_t* scratch, size_t max_chunk_bytes, Lz4Mode mode, hipStream_t stream)
+    size_t batch, int elem_size, uint32_t* scratch, uint16_t* far_tables, size_t far_capacity,
+    size_t max_chunk_bytes, Lz4Mode mode, hipStream_t stream)
 {
   const Lz4CompressShape mix = lz4_compress_shape_mix(ht_size, batch);
-  const Lz4CompressShape flat = lz4_compress_shape_flat(ht_size, batch);
-  // the flat shape only pays when it holds more chunks per CU and the batch
-  // fills the chip; it needs the ticket counter
-  const bool flat_possible = scratch != nullptr && flat.waves() * flat.groups > mix.waves() * mix.groups
-                             && batch >= (size_t)4 * mix.groups * mix.waves();
-  if (mode == Lz4Mode::Auto && !flat_possible)
+  // far: as many workgroups as the chip holds and the caller's buffer has tables for
+  Lz4CompressShape far = {};
+  far.plain = kFarWavesPerGroup;
+  far.lds_bytes = kFarWavesPerGroup * kFarScratchSlots * (uint32_t)sizeof(uint16_t);
+  far.groups = (uint32_t)num_cus_of_current_device() * kFarGroupsPerCu;
+  if ((size_t)far.groups * kFarWavesPerGroup > far_capacity)
+    far.groups = (uint32_t)(far_capacity / kFarWavesPerGroup);
+  // it needs the ticket counter, and pays once the batch is more than the mix
+  // shape has in flight at once (whose waves are the faster ones)
+  const bool far_possible = scratch != nullptr && far_tables != nullptr && far.groups > 0;
+  if (mode == Lz4Mode::Far && !far_possible) // (forced by the environment)
     mode = Lz4Mode::Mix;
-  if (mode == Lz4Mode::Flat && scratch == nullptr) // (forced by the environment: any batch that has a ticket counter)
+  if (mode == Lz4Mode::Auto
+      && !(far_possible && far.groups * far.waves() > mix.groups * mix.waves() && batch > (size_t)mix.groups * mix.waves()))
     mode = Lz4Mode::Mix;
   const hipError_t raised = raise_dynamic_lds_limit();
   if (raised != hipSuccess)
@@ -1648,7 +1862,7 @@ hipError_t lz4_launch_compress(
       per_ticket *= 2;
     return per_ticket;
   };
-  if (mode != Lz4Mode::Flat) {
+  if (mode != Lz4Mode::Far) {
     // ticket == nullptr: no persistent workgroups, one chunk per wave
     const dim3 grid(ticket ? mix.groups : (unsigned)((batch + mix.waves() - 1) / mix.waves()));
     mix_kernel_for(elem_size)<<<grid, dim3(mix.waves() * kWave), mix.lds_bytes, stream>>>(
@@ -1656,9 +1870,9 @@ hipError_t lz4_launch_compress(
         (uint32_t)batch, ticket, chunks_per_ticket(mix), chosen);
   }
   if (mode != Lz4Mode::Mix)
-    flat_kernel_for(elem_size)<<<dim3(flat.groups), dim3(flat.waves() * kWave), flat.lds_bytes, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, flat.stride_plain, (uint32_t)batch, ticket,
-        chunks_per_ticket(flat), chosen);
+    far_kernel_for(elem_size)<<<dim3(far.groups), dim3(far.waves() * kWave), far.lds_bytes, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, (uint32_t)batch, ticket,
+        chunks_per_ticket(far), chosen);
   return hipSuccess;
 }
 

@@ -13,9 +13,8 @@ namespace hcamd {
 // holds.  Four (one per SIMD): the kernel may then use up to 256 vector
 // registers and keeps clear of the accumulation registers, which its walk uses
 // by name (lz4_kernels.hip, HC_WALK_AGPRS; tests/test_build_guards_cpu.py
-// checks the build).  The "flat" shape (no walk) holds five.
+// checks the build).
 constexpr int kLz4MaxWavesPerGroup = 4;
-constexpr int kLz4FlatWavesPerGroup = 5;
 
 // Launch shape of a compression kernel: per workgroup `tagged` waves whose
 // chunk has a tag table behind its position table and `plain` waves without.
@@ -27,12 +26,11 @@ struct Lz4CompressShape
   uint32_t groups;                      // persistent workgroups
   uint32_t waves() const { return tagged + plain; }
 };
-// the shape for data with match-less stretches / for data with matches everywhere
+// the shape with the tables in LDS
 Lz4CompressShape lz4_compress_shape_mix(uint32_t ht_size, size_t batch);
-Lz4CompressShape lz4_compress_shape_flat(uint32_t ht_size, size_t batch);
 
-enum class Lz4Mode { Auto, Mix, Flat };
-// HIPCOMP_LZ4_SHAPE = auto | mix | flat (read once; default auto).  A
+enum class Lz4Mode { Auto, Mix, Far };
+// HIPCOMP_LZ4_SHAPE = auto | mix | far (read once; default auto).  A
 // measurement / test knob: the compressed bytes do not depend on it.
 Lz4Mode lz4_mode_from_environment();
 
@@ -40,11 +38,15 @@ Lz4Mode lz4_mode_from_environment();
 // memory (the head of the caller's temp buffer): the ticket counter from which
 // the waves of the persistent workgroups draw chunk numbers, and the two
 // counters of the sampling kernel that pick the shape.  nullptr = one chunk per wave,
-// as many workgroups as that takes, "mix" shape.  batch must be > 0 and < 2^31.
+// as many workgroups as that takes, "mix" shape.  `far_tables`: 16-byte aligned
+// device memory for far_capacity hash tables of max(ht_size, 8) uint16 each
+// (the rest of the temp buffer), used by the "far" shape while the call runs;
+// nullptr / 0 = never that shape.  batch must be > 0 and < 2^31.
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, uint32_t* scratch, size_t max_chunk_bytes, Lz4Mode mode, hipStream_t stream);
+    size_t batch, int elem_size, uint32_t* scratch, uint16_t* far_tables, size_t far_capacity,
+    size_t max_chunk_bytes, Lz4Mode mode, hipStream_t stream);
 
 // write_out == false: parse-only pass that reports sizes.
 void lz4_launch_decompress(

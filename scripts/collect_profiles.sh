@@ -18,14 +18,16 @@ for D in uniform harness; do
 done
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
 SQ2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-for D in uniform harness; do
-  rocprofv3 --kernel-trace --output-format csv --pmc $SQ1 -d $O/sq1_$D -- python3 scripts/quick_lz4.py --chunks 5000 --dist $D --reps 1 --count-sequences > $O/sq1_$D.log 2>&1
-  rocprofv3 --kernel-trace --output-format csv --pmc $SQ2 -d $O/sq2_$D -- python3 scripts/quick_lz4.py --chunks 5000 --dist $D --reps 1 > $O/sq2_$D.log 2>&1
+# (harness: 20000 chunks, so that the far shape has all its 8192 waves)
+for DN in uniform:5000 harness:20000; do
+  D=${DN%:*}; N=${DN#*:}
+  rocprofv3 --kernel-trace --output-format csv --pmc $SQ1 -d $O/sq1_$D -- python3 scripts/quick_lz4.py --chunks $N --dist $D --reps 1 --count-sequences > $O/sq1_$D.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc $SQ2 -d $O/sq2_$D -- python3 scripts/quick_lz4.py --chunks $N --dist $D --reps 1 > $O/sq2_$D.log 2>&1
 done
 { echo "# lz4 compress kernel (mix shape), 5000 x 64 KiB uniform chunks, per 61-byte window per wave (= per-dispatch counter / 5 375 000 windows); SQ_*CYCLES, SQ_WAIT*, SQ_ACTIVE* are quad-cycles";
   python3 scripts/pmc_per_window.py 5375000 $O/sq1_uniform $O/sq2_uniform; } > $O/${R}_lz4_pmc_per_window_uniform_char.txt
 SEQ=$(grep -o "sequences_per_chunk=[0-9.]*" $O/sq1_harness.log | cut -d= -f2)
-{ echo "# lz4 compress kernel (flat shape), 5000 x 64 KiB harness chunks (300 + (x & 3) int32 as bytes), per LZ4 sequence per wave ($SEQ sequences per chunk); quad-cycles as above";
-  python3 scripts/pmc_per_window.py $(python3 -c "print(5000*$SEQ)") $O/sq1_harness $O/sq2_harness; } > $O/${R}_lz4_pmc_per_sequence_harness_char.txt
+{ echo "# lz4 compress kernel (far shape), 20000 x 64 KiB harness chunks (300 + (x & 3) int32 as bytes), per LZ4 sequence per wave ($SEQ sequences per chunk); quad-cycles as above";
+  python3 scripts/pmc_per_window.py $(python3 -c "print(20000*$SEQ)") $O/sq1_harness $O/sq2_harness; } > $O/${R}_lz4_pmc_per_sequence_harness_char.txt
 cat $O/${R}_lz4_pmc_per_window_uniform_char.txt $O/${R}_lz4_pmc_per_sequence_harness_char.txt
 tail -c 400 $O/bench_under_rocprof.json.log

@@ -28,11 +28,11 @@ def test_compiler_leaves_the_accumulation_registers_alone(tmp_path):
     agprs = dict(re.findall(r"\.set (\S*lz4_compress_kernel_\S*)\.num_agpr, (\d+)", text))
     vgprs = dict(re.findall(r"\.set (\S*lz4_compress_kernel_\S*)\.num_vgpr, (\d+)", text))
     mix = [k for k in agprs if "kernel_mix" in k]
-    flat = [k for k in agprs if "kernel_flat" in k]
-    assert len(mix) == 3 and len(flat) == 3      # element size 1, 2, 4
+    far = [k for k in agprs if "kernel_far" in k]
+    assert len(mix) == 3 and len(far) == 3       # element size 1, 2, 4
     assert {agprs[k] for k in mix} == {"24"}     # the walk's own, nothing of the compiler's
-    assert {agprs[k] for k in flat} == {"0"}     # no walk
-    assert all(int(vgprs[k]) <= 128 for k in flat)   # five waves per workgroup = two on one SIMD
+    assert {agprs[k] for k in far} == {"0"}      # no walk
+    assert all(int(vgprs[k]) <= 64 for k in far)     # 32 waves per CU = eight on one SIMD
     assert all(int(vgprs[k]) <= 256 for k in mix)
     spills = re.findall(r"\.set \S*lz4_compress_kernel_\S*\.private_seg_size, (\d+)", text)
     assert spills and set(spills) == {"0"}       # nothing spilled to scratch memory either

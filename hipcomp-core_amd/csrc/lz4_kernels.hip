@@ -1513,89 +1513,111 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
   const uint32_t cap = WRITE_OUT ? uniform((uint32_t)out_caps[chunk]) : 0xFFFFFFFFu;
   gptr out = WRITE_OUT ? to_global(uniform_ptr(out_ptrs[chunk])) : nullptr;
 
-  uint32_t c = 0, d = 0;
+  // Issue slots, not latency, bound this kernel on data that compresses: a CU
+  // runs 32 of these waves and each SIMD issues one scalar and one vector
+  // instruction per four cycles, so a sequence costs max(scalar, vector
+  // instructions) x 32 cycles on its CU.  Left alone the compiler computes
+  // everything wave-uniform -- the whole parse -- on the scalar unit (58 scalar
+  // against 21 vector instructions per sequence, profiles/r02_lz4_pmc_per_
+  // sequence_decompress.txt).  Hence: the output position d lives in a vector
+  // register (vd, same value in all lanes, see in_vector_register) and so does
+  // everything computed from it, and the conditions of the fast paths are
+  // folded into one sign bit each instead of a mask per compare.
+  uint32_t c = 0, vd = 0;
+  // (positions stay below 2^31, so that differences can be tested by sign)
+  const uint32_t capc = min(cap, 0x7FFFFFFFu);
   bool corrupt = false;
   // Short sequences are parsed from a register window of the stream
   // (StreamWindow), i.e. without a memory round trip in the chain that leads
   // from one token to the next.
   StreamWindow sw;
-  while (c < end) {
+  for (;;) {
     uint32_t tok = 0;
-    bool tok_known = false;
     // ---- fast paths: token, up to 14 literals, offset and at most one match
     // length byte inside the stream; literals + match at most 64 bytes (one
-    // byte per lane).  Anything else takes the general path below.
-    if (c + kFastSeqBytes <= end) {
+    // byte per lane).  The loop is left at the first sequence that is anything
+    // else: it takes the general path below.
+    while (c + kFastSeqBytes <= end) {
       sw.ensure(comp, c, end, kFastSeqBytes, lane);
       const uint32_t idx = c - sw.base;
-      tok = sw.bytes_at(idx) & 0xFFu;
-      tok_known = true;
-      const uint32_t litf = tok >> 4, mlc = tok & 15u;
-      if (litf < 15u) { // literal length in the token itself
+      const uint32_t tw = read_lane(sw.words, (int)(idx >> 2)) >> ((idx & 3u) * 8u); // token = low byte
+      tok = tw & 0xFFu;
+      const uint32_t litf = (tw >> 4) & 15u;
+      if (litf == 15u)
+        break;
+      { // literal length in the token itself
         // offset (2 bytes) and the byte behind it: a length byte if the
         // token's match field is 15
-        const uint32_t t2 = sw.bytes_at(idx + 1u + litf);
-        const uint32_t off = t2 & 0xFFFFu;
+        const uint32_t vt2 = in_vector_register(sw.bytes_at(idx + 1u + litf));
+        const uint32_t vmlc = in_vector_register(tw) & 15u;
+        const uint32_t voff = vt2 & 0xFFFFu;
+        const uint32_t vml1 = vmlc + 4u;
+        const uint32_t vdl = vd + litf;
         // One byte per lane for literals AND match: lane i < lit carries
         // literal i, lane lit + j match byte j.  `a` is the source as an index
         // relative to d: >= 0 means a literal of this very sequence, i.e. a
         // byte of the stream window (for match bytes too: no round trip
         // through the output); < 0 means earlier output.
         const uint32_t i = (uint32_t)lane;
-        // (1) the common one: match length in the token, output fits, offset
-        // inside what exists, source and destination do not overlap
-        const uint32_t ml1 = mlc + 4u;
-        if ((mlc < 15u) & (d + litf + ml1 <= cap) & (off != 0u) & (off <= d + litf) & (off >= ml1)) {
+        // (1) the common one: match length in the token (mlc < 15), output
+        // fits (d + lit + ml <= cap), offset inside what exists (0 < off <=
+        // d + lit), source and destination do not overlap (off >= ml)
+        const uint32_t bad1
+            = (14u - vmlc) | (capc - (vdl + vml1)) | (voff - 1u) | (vdl - voff) | (voff - vml1);
+        if (wave_ballot((int32_t)bad1 < 0) == 0) {
           if (WRITE_OUT) {
-            const int32_t a = (int32_t)(i - (i < litf ? 0u : off));
+            const int32_t a = (int32_t)(i - (i < litf ? 0u : voff));
             const uint32_t sidx = idx + 1u + (uint32_t)max(a, 0);
             const uint32_t sword = (uint32_t)__builtin_amdgcn_ds_bpermute(
                 (int)((sidx >> 2) * 4u), (int)sw.words);
-            uint32_t byte = sword >> ((sidx & 3u) * 8u);
-            if (off > litf) { // some match bytes come from earlier output
-              // Earlier stores of this wave to out[] are ordered before this
-              // load (one wave, in-order vector memory, one L1).
-              const uint32_t gb = *(static_cast<cgptr>(out + d) + min(a, -1));
-              byte = a >= 0 ? byte : gb;
-            }
-            if (i < litf + ml1)
-              out[d + i] = (uint8_t)byte;
+            const uint32_t byte = sword >> ((sidx & 3u) * 8u);
+            // Earlier output: loaded whether or not a lane needs it (cheaper
+            // than a branch) from an index clamped into the buffer.  Earlier
+            // stores of this wave to out[] are ordered before this load (one
+            // wave, in-order vector memory, one L1).
+            const uint32_t gb = static_cast<cgptr>(out)[max((int32_t)(vd + (uint32_t)min(a, -1)), 0)];
+            if (i < litf + vml1)
+              out[vd + i] = (uint8_t)(a >= 0 ? byte : gb);
           }
-          c += 1u + litf + 2u;
-          d += litf + ml1;
+          c += 3u + litf;
+          vd = vdl + vml1;
           continue;
         }
         // (2) one length byte (not 255: a second one would follow) and / or
-        // a match that overlaps itself: its source repeats with period `off`
-        const bool has_ext = mlc == 15u;
-        const uint32_t ext = (t2 >> 16) & 0xFFu;
-        const uint32_t ml2 = ml1 + (has_ext ? ext : 0u);
-        const uint32_t n2 = litf + ml2;
-        if (!(has_ext & (ext == 255u)) & (n2 <= (uint32_t)kWave) & (d + n2 <= cap) & (off != 0u)
-            & (off <= d + litf)) {
+        // a match that overlaps itself: its source repeats with period `off`.
+        // n2 <= 64, d + n2 <= cap, 0 < off <= d + lit
+        const uint32_t vext = (vt2 >> 16) & 0xFFu;
+        const uint32_t vml2 = vml1 + (vmlc == 15u ? vext : 0u);
+        const uint32_t vn2 = vml2 + litf;
+        const uint32_t bad2 = ((vmlc == 15u) & (vext == 255u) ? ~0u : 0u) | ((uint32_t)kWave - vn2)
+                              | (capc - (vd + vn2)) | (voff - 1u) | (vdl - voff);
+        if (wave_ballot((int32_t)bad2 < 0) == 0) {
           if (WRITE_OUT) {
             uint32_t j = i - litf; // match byte index (lanes >= lit)
-            if (off < ml2)
-              j = small_mod(j & 63u, off); // (lanes below lit: unused)
-            const int32_t a = i < litf ? (int32_t)i : (int32_t)(litf + j - off);
+            if (wave_ballot(voff < vml2) != 0)
+              j = small_mod(j & 63u, voff); // (lanes below lit: unused)
+            const int32_t a = i < litf ? (int32_t)i : (int32_t)(litf + j - voff);
             const uint32_t sidx = idx + 1u + (uint32_t)max(a, 0);
             const uint32_t sword = (uint32_t)__builtin_amdgcn_ds_bpermute(
                 (int)((sidx >> 2) * 4u), (int)sw.words);
-            uint32_t byte = sword >> ((sidx & 3u) * 8u);
-            if (off > litf) {
-              const uint32_t gb = *(static_cast<cgptr>(out + d) + min(a, -1));
-              byte = a >= 0 ? byte : gb;
-            }
-            if (i < n2)
-              out[d + i] = (uint8_t)byte;
+            const uint32_t byte = sword >> ((sidx & 3u) * 8u);
+            const uint32_t gb = static_cast<cgptr>(out)[max((int32_t)(vd + (uint32_t)min(a, -1)), 0)];
+            if (i < vn2)
+              out[vd + i] = (uint8_t)(a >= 0 ? byte : gb);
           }
-          c += 1u + litf + 2u + (has_ext ? 1u : 0u);
-          d += n2;
+          c += 3u + litf + ((tw & 15u) == 15u ? 1u : 0u);
+          vd += vn2;
           continue;
         }
       }
+      break;
     }
-    if (!tok_known)
+    if (c >= end)
+      break;
+    // ---- general path: everything scalar again
+    uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)vd);
+    // (the fast loop was left either at a token it had read or short of the end)
+    if (c + kFastSeqBytes > end)
       tok = uniform((uint32_t)comp[c]);
     ++c;
     uint32_t lit = tok >> 4;
@@ -1661,10 +1683,11 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
       }
       d += ml;
     }
+    vd = d;
   }
   if (lane == 0) {
     if (actual_bytes)
-      actual_bytes[chunk] = corrupt ? 0 : d; // reference :1088-1096
+      actual_bytes[chunk] = corrupt ? 0 : vd; // reference :1088-1096
     if (WRITE_OUT && statuses)
       statuses[chunk] = corrupt ? hipcompErrorCannotDecompress : hipcompSuccess;
   }

@@ -201,6 +201,15 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t j, uint32_t m)
   return (uint32_t)rem;
 }
 
+// A wave-uniform value moved into a vector register, where it and whatever is
+// computed from it stay: the compiler computes anything it can prove uniform
+// on the scalar unit, of which a CU has one for all its waves.
+__device__ __forceinline__ uint32_t in_vector_register(uint32_t x)
+{
+  asm("" : "+v"(x));
+  return x;
+}
+
 // ---------------------------------------------------------------------------
 // 256 bytes of a byte stream in registers: lane t holds the dword at stream
 // index base + 4t (any alignment).  A decoder reads its tags / tokens /
@@ -210,15 +219,16 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t j, uint32_t m)
 struct StreamWindow
 {
   uint32_t words = 0; // per lane
-  uint32_t base = 0;  // stream index of lane 0's dword (wave-uniform)
-  bool valid = false;
+  // stream index of lane 0's dword (wave-uniform); initially out of reach of
+  // any position below 2^31, i.e. the first ensure() fills the window
+  uint32_t base = 0x80000000u;
 
   // Makes the window cover [pos, pos + reach + 8).  Needs pos < end, end >= 4
   // and reach <= 64: `reach` is how far past pos the caller will ask for bytes
   // before calling ensure() the next time.
   __device__ __forceinline__ void ensure(cgptr stream, uint32_t pos, uint32_t end, uint32_t reach, int lane)
   {
-    if (!valid || pos - base > 256u - 8u - reach) {
+    if (pos - base > 256u - 8u - reach) {
       base = pos;
       // Lanes whose dword would reach past the end of the stream load the
       // last dword of the stream instead (end >= 4 here) and shift it into
@@ -230,7 +240,6 @@ struct StreamWindow
       // wait here: left to the compiler the wait lands after the branch, where
       // it would also wait for the caller's last store every time
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-      valid = true;
     }
   }
 

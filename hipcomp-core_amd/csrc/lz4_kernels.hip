@@ -1340,34 +1340,39 @@ __device__ __forceinline__ void compress_wave_far(
         window_begin<S, NVMAX>(P, d, next, L, hmask, lane);
         // Table slots of the first kFarFirst lanes only: that is where the match
         // of a window of compressible data is, and a slot costs a memory
-        // transaction.  (In flight while the duplicates are looked for.)
+        // transaction.
         P.h_old = kNullOffset;
         if (lane < kFarFirst)
           P.h_old = table[P.hpos];
         P.t_old = 0;
-        const uint32_t ks = P.hpos & (kFarScratchSlots - 1u);
-        const uint32_t pr = (uint32_t)__builtin_amdgcn_ds_bpermute(
-            rev_addr4, (int)(ks | (P.valid ? 0x80000000u : 0u)));
-        lds_lane_exchange_fence();
-        if (pr & 0x80000000u)
-          scr[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
-        lds_lane_exchange_fence();
-        P.w_raw = scr[ks];
-        lds_lane_exchange_fence();
-        const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
-            (int)(window_winner(P, lane) * 4u), (int)P.word);
-        int f;
-        uint32_t mlane;
-        window_first_duplicate<NVMAX>(P, nw, lane, f, mlane);
         window_candidate<S>(P, no_tags, in, last_word, lane, cold > 0);
-        uint64_t tmask = window_table_matches<NVMAX>(P, f);
-        if (tmask == 0 && f > kFarFirst) {
-          // no match among the first lanes: the slots of the lanes up to f
-          P.h_old = kNullOffset;
-          if (lane >= kFarFirst && lane < f)
-            P.h_old = table[P.hpos];
-          window_candidate<S>(P, no_tags, in, last_word, lane, false);
-          tmask = window_table_matches<NVMAX>(P, f);
+        uint64_t tmask = window_table_matches<NVMAX>(P, P.nv);
+        int f = 0;
+        uint32_t mlane = 0;
+        // A table match of lane 0 is the decision: no lane is earlier.  Else
+        // the duplicates inside the window are looked for.
+        if (!(tmask & 1ull)) {
+          const uint32_t ks = P.hpos & (kFarScratchSlots - 1u);
+          const uint32_t pr = (uint32_t)__builtin_amdgcn_ds_bpermute(
+              rev_addr4, (int)(ks | (P.valid ? 0x80000000u : 0u)));
+          lds_lane_exchange_fence();
+          if (pr & 0x80000000u)
+            scr[pr & 0x7FFFFFFFu] = (uint16_t)rev_lane;
+          lds_lane_exchange_fence();
+          P.w_raw = scr[ks];
+          lds_lane_exchange_fence();
+          const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(
+              (int)(window_winner(P, lane) * 4u), (int)P.word);
+          window_first_duplicate<NVMAX>(P, nw, lane, f, mlane);
+          tmask &= lanes_below<NVMAX>(f);
+          if (tmask == 0 && f > kFarFirst) {
+            // no match among the first lanes: the slots of the lanes up to f
+            P.h_old = kNullOffset;
+            if (lane >= kFarFirst && lane < f)
+              P.h_old = table[P.hpos];
+            window_candidate<S>(P, no_tags, in, last_word, lane, false);
+            tmask = window_table_matches<NVMAX>(P, f);
+          }
         }
         const Decision D = window_settle(P, f, mlane, tmask);
         if (D.match) {
@@ -1562,8 +1567,8 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
         // (1) the common one: match length in the token (mlc < 15), output
         // fits (d + lit + ml <= cap), offset inside what exists (0 < off <=
         // d + lit), source and destination do not overlap (off >= ml)
-        const uint32_t bad1
-            = (14u - vmlc) | (capc - (vdl + vml1)) | (voff - 1u) | (vdl - voff) | (voff - vml1);
+        // (off >= ml >= 4 says off != 0)
+        const uint32_t bad1 = (14u - vmlc) | (capc - (vdl + vml1)) | (vdl - voff) | (voff - vml1);
         if (wave_ballot((int32_t)bad1 < 0) == 0) {
           if (WRITE_OUT) {
             const int32_t a = (int32_t)(i - (i < litf ? 0u : voff));
@@ -1571,13 +1576,15 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
             const uint32_t sword = (uint32_t)__builtin_amdgcn_ds_bpermute(
                 (int)((sidx >> 2) * 4u), (int)sw.words);
             const uint32_t byte = sword >> ((sidx & 3u) * 8u);
-            // Earlier output: loaded whether or not a lane needs it (cheaper
-            // than a branch) from an index clamped into the buffer.  Earlier
+            // Earlier output: loaded whether or not the lane needs it (cheaper
+            // than a branch); d + a lies inside the buffer for every lane that
+            // stores (0 <= d + lit - off, d + a < d + lit + ml <= cap).  Earlier
             // stores of this wave to out[] are ordered before this load (one
             // wave, in-order vector memory, one L1).
-            const uint32_t gb = static_cast<cgptr>(out)[max((int32_t)(vd + (uint32_t)min(a, -1)), 0)];
-            if (i < litf + vml1)
+            if (i < litf + vml1) {
+              const uint32_t gb = static_cast<cgptr>(out)[vd + (uint32_t)a];
               out[vd + i] = (uint8_t)(a >= 0 ? byte : gb);
+            }
           }
           c += 3u + litf;
           vd = vdl + vml1;
@@ -1601,9 +1608,10 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
             const uint32_t sword = (uint32_t)__builtin_amdgcn_ds_bpermute(
                 (int)((sidx >> 2) * 4u), (int)sw.words);
             const uint32_t byte = sword >> ((sidx & 3u) * 8u);
-            const uint32_t gb = static_cast<cgptr>(out)[max((int32_t)(vd + (uint32_t)min(a, -1)), 0)];
-            if (i < vn2)
+            if (i < vn2) {
+              const uint32_t gb = static_cast<cgptr>(out)[vd + (uint32_t)a];
               out[vd + i] = (uint8_t)(a >= 0 ? byte : gb);
+            }
           }
           c += 3u + litf + ((tw & 15u) == 15u ? 1u : 0u);
           vd += vn2;

@@ -279,8 +279,11 @@ __global__ __launch_bounds__(256) void snappy_get_sizes_kernel(
 constexpr int kDecompWavesPerBlock = 4;
 
 // How far past an element's tag the decoder looks in the register window
-// before it asks for the window again (the tag and 3 bytes behind it).
-constexpr uint32_t kSnappyWindowReach = 4;
+// before it asks for the window again: the tag and the 60 literal bytes or the
+// offset bytes behind it.
+constexpr uint32_t kSnappyWindowReach = 64;
+// Least bytes of stream left for the window to be used (tag + 3).
+constexpr uint32_t kSnappyWindowMin = 4;
 
 __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompress_kernel(
     const uint8_t* const* __restrict__ comp_ptrs,
@@ -289,6 +292,21 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
     uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
     hipcompStatus_t* __restrict__ statuses)
 {
+  // What a tag byte says, looked up instead of computed (the parse below is
+  // bound by its vector instruction count): output bytes | stream bytes << 8 |
+  // literal << 16 | 1-byte-offset copy << 17 | not for the fast path << 31
+  // (4-byte offset, literal with a length field).
+  __shared__ uint32_t tag_lut[256];
+  static_assert(kWave * kDecompWavesPerBlock == 256, "one tag per thread");
+  {
+    const uint32_t b = threadIdx.x, kind = b & 3u, n6 = b >> 2;
+    const bool lit = kind == 0u, c1 = kind == 1u;
+    const uint32_t blen = c1 ? (n6 & 7u) + 4u : n6 + 1u;
+    const uint32_t need = lit ? 1u + blen : kind + 1u;
+    const bool slow = kind == 3u || (lit && n6 >= 60u);
+    tag_lut[b] = blen | (need << 8) | (lit ? 1u << 16 : 0u) | (c1 ? 1u << 17 : 0u) | (slow ? 1u << 31 : 0u);
+  }
+  __syncthreads();
   const int lane = lane_id();
   // everything that steers the parse is wave-uniform: say so (see uniform())
   const size_t chunk = (size_t)blockIdx.x * kDecompWavesPerBlock + uniform((uint32_t)(threadIdx.x >> 6));
@@ -316,26 +334,68 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
     if (error) {
       usize = 0; // the reference reports size - bytes_left = 0 here
     } else {
-      bytes_left = usize;
-      uint32_t dst_pos = 0;
-      StreamWindow sw;
-      while (bytes_left > 0) {
-        if (cur >= end)
-          break;
-        // Tag byte and the three bytes behind it, wave-uniform: from the
-        // register window of the stream (no memory round trip in the chain
-        // from one element to the next), near the end of the stream from
-        // memory.  Bytes past the end read as 0; every use is guarded by a
-        // length check.
-        uint32_t t;
-        if (end - cur >= kSnappyWindowReach) {
-          sw.ensure(comp, cur, end, kSnappyWindowReach, lane);
-          t = sw.bytes_at(cur - sw.base);
-        } else {
-          t = uniform((uint32_t)comp[cur]);
-          for (uint32_t i = 1; i < 4 && cur + i < end; ++i)
-            t |= uniform((uint32_t)comp[cur + i]) << (8 * i);
+      // Issue slots bound this kernel (32 waves per CU; a SIMD issues one
+      // scalar and one vector instruction per ~4 cycles) and left alone the
+      // compiler runs the whole wave-uniform parse on the scalar unit (59
+      // scalar against 6 vector instructions per element in round 1).  So the
+      // three positions live in vector registers -- same value in all lanes,
+      // see in_vector_register -- the stream window is read with ds_bpermute,
+      // the element kinds are told apart by selects instead of branches and
+      // all that can go wrong is folded into one sign test.
+      uint32_t vcur = in_vector_register(cur), vdst = in_vector_register(0u);
+      uint32_t vleft = in_vector_register(usize);
+      const uint32_t i = (uint32_t)lane;
+      StreamWindowV sw;
+      for (;;) {
+        // ---- elements with a one-byte length: literals of up to 60 bytes,
+        // copies with 1- and 2-byte offsets, at least 4 bytes of stream left
+        for (;;) {
+          const uint32_t avail = end - vcur; // (cur <= end always)
+          if (wave_ballot((int32_t)((vleft - 1u) | (avail - kSnappyWindowMin)) < 0) != 0)
+            break;
+          sw.ensure(comp, vcur, end, kSnappyWindowReach, lane);
+          const uint32_t t = sw.bytes_at(vcur - sw.base);
+          const uint32_t e = tag_lut[t & 0xFFu];
+          const uint32_t blen = e & 0xFFu, need = (e >> 8) & 0xFFu;
+          const bool lit = (e & (1u << 16)) != 0u;
+          const uint32_t off16 = (t >> 8) & 0xFFFFu;
+          const uint32_t offset = (e & (1u << 17)) ? ((t & 0xe0u) << 3) | (off16 & 0xFFu) : off16;
+          // tag for this path; fits what is left of the output and of the
+          // stream; copy: 0 < offset <= dst
+          const uint32_t bad = e | (vleft - blen) | (avail - need) | (lit ? 0u : (offset - 1u) | (vdst - offset));
+          if (wave_ballot((int32_t)bad < 0) != 0)
+            break;
+          // one byte per lane.  Copies: lane % offset -- for offset >= blen (no
+          // overlap) that is the lane.  Earlier stores of this wave to out[]
+          // are ordered before these loads (one wave, in-order vector memory,
+          // one L1).
+          uint32_t k = i;
+          if (wave_ballot(!lit && offset < blen) != 0)
+            k = small_mod(i, offset);
+          // literal bytes come from the register window (it reaches 64 bytes
+          // past the tag), copy bytes from out[]; a literal's lanes load their
+          // own destination byte instead (inside the buffer, value unused)
+          const uint32_t widx = vcur - sw.base + 1u + i;
+          const uint32_t wword = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(widx & ~3u), (int)sw.words);
+          if (i < blen) {
+            const uint32_t ob = static_cast<cgptr>(out)[lit ? vdst + i : vdst - offset + k];
+            out[vdst + i] = (uint8_t)(lit ? wword >> ((widx & 3u) * 8u) : ob);
+          }
+          vcur += need;
+          vdst += blen;
+          vleft -= blen;
         }
+        // ---- anything else, one element: scalar again
+        uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)vcur);
+        uint32_t dst_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vdst);
+        bytes_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)vleft);
+        if (bytes_left == 0 || cur >= end)
+          break;
+        // tag byte and the three bytes behind it; bytes past the end read as
+        // 0, every use is guarded by a length check
+        uint32_t t = uniform((uint32_t)comp[cur]);
+        for (uint32_t j = 1; j < 4 && cur + j < end; ++j)
+          t |= uniform((uint32_t)comp[cur + j]) << (8 * j);
         const uint32_t b0 = t & 0xFFu;
         uint32_t blen, offset;
         if (b0 & 3u) {
@@ -360,11 +420,7 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
           }
           if (offset == 0 || offset > dst_pos || bytes_left < blen)
             break;
-          // blen <= 64: one step, one byte per lane.  Earlier stores of this
-          // wave to out[] are ordered before these loads (one wave, in-order
-          // vector memory, one L1).
           if ((uint32_t)lane < blen) {
-            // (lane % offset; for offset >= blen, i.e. no overlap, that is lane)
             const uint32_t k = small_mod((uint32_t)lane, offset);
             out[dst_pos + lane] = out[dst_pos - offset + k];
           }
@@ -376,8 +432,8 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
             if (end - cur < nb)
               break;
             blen = 0;
-            for (uint32_t i = 0; i < nb; ++i)
-              blen |= uniform((uint32_t)comp[cur + i]) << (8 * i);
+            for (uint32_t j = 0; j < nb; ++j)
+              blen |= uniform((uint32_t)comp[cur + j]) << (8 * j);
             cur += nb;
           }
           blen += 1;
@@ -391,9 +447,11 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
           }
           cur += blen;
         }
-        dst_pos += blen;
-        bytes_left -= blen;
+        vcur = cur;
+        vdst = dst_pos + blen;
+        vleft = bytes_left - blen;
       }
+      bytes_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)vleft);
       if (bytes_left != 0)
         error = true;
     }

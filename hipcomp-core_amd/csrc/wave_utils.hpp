@@ -252,4 +252,35 @@ struct StreamWindow
   }
 };
 
+// The same window for a decoder that keeps its stream position in a vector
+// register (wave-uniform all the same, see in_vector_register): the window is
+// read with ds_bpermute instead of v_readlane, so that no step of the parse
+// runs on the scalar unit.
+struct StreamWindowV
+{
+  uint32_t words = 0;          // per lane
+  uint32_t base = 0x80000000u; // stream index of lane 0's dword, same in all lanes
+
+  // Makes the window cover [pos, pos + reach + 8); needs pos < end, end >= 4, reach <= 64.
+  __device__ __forceinline__ void ensure(cgptr stream, uint32_t pos, uint32_t end, uint32_t reach, int lane)
+  {
+    if (wave_ballot(pos - base > 256u - 8u - reach) != 0) {
+      base = pos;
+      const uint32_t at = pos + 4u * (uint32_t)lane;
+      const uint32_t over = at > end - 4u ? at - (end - 4u) : 0u; // bytes
+      const uint32_t raw = load_u32_any(stream + (at - over));
+      words = over >= 4u ? 0u : raw >> (8u * over);
+    }
+  }
+
+  // 4 bytes at byte index idx (< 252) of the window
+  __device__ __forceinline__ uint32_t bytes_at(uint32_t idx) const
+  {
+    const uint32_t q4 = idx & ~3u;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)q4, (int)words);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q4 + 4u), (int)words);
+    return __builtin_amdgcn_alignbyte(hi, lo, idx & 3u);
+  }
+};
+
 } // namespace hcamd

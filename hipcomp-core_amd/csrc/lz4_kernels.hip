@@ -1213,6 +1213,9 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
 // ---------------------------------------------------------------------------
 constexpr int kFarWavesPerGroup = 4;
 constexpr int kFarFirst = 8; // lanes whose table slots are looked up before the rest
+// Elements a window must have ahead of it for the straight-line path: the
+// window, the lanes of the match, 256 bytes of match length, the chunk's tail.
+constexpr uint32_t kFarFastMargin = 400;
 constexpr int kFarGroupsPerCu = 8; // 32 waves: 64 vector registers each
 constexpr uint32_t kFarScratchSlots = 2048; // u16 each, per wave: 128 KiB per CU
 
@@ -1331,7 +1334,78 @@ __device__ __forceinline__ void compress_wave_far(
         next = load_u32_any(in + (size_t)min((uint32_t)lane, last_word) * S);
       int cold = 0;
       uint32_t token_start = 0;
+      // the straight-line path below is tried while it keeps finding its kind of window
+      bool straight = true;
       while (d < L) {
+        // ---- the common window of data that compresses, as straight a line
+        // as it can be written (this kernel is bound by its instruction
+        // count, the scalar one above all: 8 waves share a SIMD's issue
+        // slots): no literals pending, a table match of one of the first
+        // kFarFirst lanes, no duplicate among the lanes below it, a short
+        // match.  Nothing is changed before all of that is known; a window
+        // that is anything else is redone by the general code below, and if
+        // it had no such table match at all (data of another kind: runs) this
+        // path rests until the general code meets one.
+        while (straight && token_start == d && d + kFarFastMargin <= L) {
+          const uint32_t word = next;
+          const uint32_t hpos = hash_sum(word) & hmask;
+          uint32_t h_old = kNullOffset;
+          if (lane < kFarFirst)
+            h_old = table[hpos];
+          const uint32_t pos = d + (uint32_t)lane;
+          const uint32_t back = (pos - 1u - h_old) & 0xFFFFu; // (see window_candidate)
+          const uint32_t cand = pos - 1u - back;
+          const bool usable = (h_old != kNullOffset) & (back < 65535u / S);
+          const uint32_t cand_word = load_u32_any(in + (size_t)(usable ? cand : pos) * S);
+          const uint64_t tmask = wave_ballot(usable & (cand_word == word));
+          if (tmask == 0) {
+            straight = false;
+            break;
+          }
+          const int k = __builtin_ctzll(tmask); // < kFarFirst
+          // a duplicate among lanes 0..k-1 would come first
+          bool duplicate = false;
+          for (int u = 0; u + 1 < k; ++u)
+            duplicate |= (wave_ballot(word == read_lane(word, u)) & lanes_below<64>(k) & ~lanes_below<64>(u + 1)) != 0;
+          if (duplicate)
+            break;
+          const uint32_t mloc = read_lane(cand, k), mpos = d + (uint32_t)k;
+          // match length: the first 256 bytes (the margin keeps them inside the limit)
+          const uint32_t x = load_u32_any(in + (size_t)mloc * S + 4u * (uint32_t)lane)
+                             ^ load_u32_any(in + (size_t)mpos * S + 4u * (uint32_t)lane);
+          const uint32_t diff_at = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+          const uint64_t stop = wave_ballot(diff_at < 4u);
+          if (stop == 0)
+            break;
+          const int sl = __builtin_ctzll(stop);
+          const uint32_t ml = (4u * (uint32_t)sl + read_lane(diff_at, sl)) / S;
+          const uint32_t lit_bytes = (uint32_t)k * S, match_bytes = ml * S;
+          if (lit_bytes >= 15u || match_bytes >= 19u)
+            break;
+          // ---- decided: insert the first k lanes, write the sequence (as
+          // emit_match's short form), move on
+          if (k > 0)
+            far_store_masked(table, hpos, pos & 0xFFFFu, slot_tops(hpos, lanes_below<64>(k), scr, lane), lane);
+          {
+            const uint32_t offset_bytes = (((mpos - mloc) & 0xFFFFu) * S) & 0xFFFFu;
+            const uint32_t i = (uint32_t)lane, li = i - 1u;
+            const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((li / S) * 4u), (int)word);
+            uint32_t bt = (src >> (8u * (li % S))) & 0xFFu;
+            if (i == 0)
+              bt = (lit_bytes << 4) | ((match_bytes - 4u) & 0x0Fu);
+            else if (i == lit_bytes + 1)
+              bt = offset_bytes & 0xFFu;
+            else if (i == lit_bytes + 2)
+              bt = offset_bytes >> 8;
+            if (i < lit_bytes + 3)
+              out[c + i] = (uint8_t)bt;
+            c += lit_bytes + 3;
+          }
+          d = mpos + ml;
+          token_start = d;
+          cold = 0;
+          next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+        }
         if (d + LVM >= L) {
           c = write_sequence(out, c, in + (size_t)token_start * S, len - token_start * S, 0, 0, lane);
           break;
@@ -1375,6 +1449,7 @@ __device__ __forceinline__ void compress_wave_far(
           }
         }
         const Decision D = window_settle(P, f, mlane, tmask);
+        straight |= tmask != 0 && D.f < kFarFirst;
         if (D.match) {
           far_insert_first<NVMAX>(P, table, scr, D.f, perm_addr4, sig, hmask, lane);
           emit_match<S>(out, c, in, token_start, P.d, P.word, D, L, lane, d);

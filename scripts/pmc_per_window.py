@@ -1,19 +1,22 @@
 """Per-window (or per-sequence) PMC figures of the LZ4 compress kernel from rocprofv3 --pmc passes.
-usage: pmc_per_window.py [--decompress] <units per dispatch> <dir> [<dir> ...]   (dirs hold *_counter_collection.csv)
+usage: pmc_per_window.py [--decompress | --kernel NAME] <units per dispatch> <dir> [<dir> ...]   (dirs hold *_counter_collection.csv)
 Prints counter value / units, averaged over the dispatches of the compress (or decompress) kernel that did
 the work (with the shape picked per call, the launch of the other shape leaves at once: it is left out)."""
 import csv, glob, os, re, sys
-which = "compress"
+which = "lz4_compress"
 if sys.argv[1] == "--decompress":
-    which = "decompress"
+    which = "lz4_decompress"
     del sys.argv[1]
+elif sys.argv[1] == "--kernel":      # e.g. --kernel snappy_compress
+    which = sys.argv[2]
+    del sys.argv[1:3]
 units = float(sys.argv[1])
 acc = {}
 for d in sys.argv[2:]:
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                m = re.search(r"lz4_" + which + r"_kernel\w*(<\w+>)?", r["Kernel_Name"])
+                m = re.search(which + r"_kernel\w*(<\w+>)?", r["Kernel_Name"])
                 if m:
                     acc.setdefault(r["Counter_Name"], {}).setdefault(m.group(0), []).append(float(r["Counter_Value"]))
 for c in sorted(acc):

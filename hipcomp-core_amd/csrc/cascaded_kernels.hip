@@ -26,6 +26,7 @@
 // SURVEY.md App. C.4) are written as 0 here, so the output is deterministic.
 
 #include "cascaded_launch.hpp"
+#include "lz4_launch.hpp" // num_cus_of_current_device
 #include "wave_utils.hpp"
 
 #include <type_traits>
@@ -444,6 +445,12 @@ __device__ __forceinline__ int wave_read_array(
 }
 
 template <int S, int CB>
+__device__ __forceinline__ void cascaded_decode_partition(
+    const uint8_t* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes_arr,
+    const size_t* __restrict__ out_caps, uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
+    hipcompStatus_t* __restrict__ statuses, const size_t part, uint8_t* const smem, const int lane);
+
+template <int S, int CB>
 __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
     const uint8_t* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes_arr,
@@ -451,33 +458,55 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
     uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
     hipcompStatus_t* __restrict__ statuses)
 {
-  typedef typename UIntOf<S>::type UT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // dec_lds_bytes<S, CB>()
   const int lane = lane_id();
-  const size_t part = blockIdx.x;
-  if (part >= batch)
-    return;
-  cgptr comp = to_global(uniform_ptr(comp_ptrs[part]));
-  const size_t comp_bytes64 = uniform((uint64_t)comp_bytes_arr[part]);
-  const bool bad_header = comp == nullptr || comp_bytes64 < kPartMeta;
-  uint32_t type = 0xFFu;
-  if (!bad_header)
-    type = uniform((uint32_t)comp[3]);
   // Each width and sub-chunk size has its own launch (the LDS a wave needs
   // depends on both); a partition is handled by the launch that matches ITS
   // type byte (the reference dispatches on partition 0 only) and ITS sub-chunk
   // code.  Undecodable headers are reported by the 1-byte 4096 launch.
-  uint32_t code = 0;
-  if (!bad_header)
+  // A launch is a fixed number of waves (as many as its LDS lets the chip
+  // hold); wave w takes partitions w, w + waves, ...  The headers of the next
+  // 64 of them are looked at together, one per lane, so that a launch with
+  // nothing to do is over after batch / (64 x waves) steps.
+  const size_t waves = gridDim.x;
+  for (size_t first = blockIdx.x; first < batch; first += kWave * waves) {
+    const size_t p = first + (size_t)lane * waves;
+    bool mine = false;
+    if (p < batch) {
+      cgptr comp = to_global(comp_ptrs[p]);
+      const bool bad_header = comp == nullptr || comp_bytes_arr[p] < kPartMeta;
+      const uint32_t type = bad_header ? 0xFFu : (uint32_t)comp[3];
+      const uint32_t code = bad_header ? 0u : (uint32_t)comp[2] >> 4;
+      constexpr uint32_t kCode = CB == 8192 ? 1u : CB == 16384 ? 2u : 0u;
+      mine = (bad_header || type > 7 || code > 2)
+                 ? (S == 1 && kCode == 0)
+                 : (code == kCode
+                    && ((S == 1 && type <= 1) || (S == 2 && (type == 2 || type == 3))
+                        || (S == 4 && (type == 4 || type == 5)) || (S == 8 && (type == 6 || type == 7))));
+    }
+    for (uint64_t todo = wave_ballot(mine); todo != 0; todo &= todo - 1)
+      cascaded_decode_partition<S, CB>(comp_ptrs, comp_bytes_arr, out_caps, out_ptrs, actual_bytes, statuses,
+                                       first + (size_t)__builtin_ctzll(todo) * waves, smem, lane);
+  }
+}
+
+// One partition, by one wave (the launch that owns its width and sub-chunk size).
+template <int S, int CB>
+__device__ __forceinline__ void cascaded_decode_partition(
+    const uint8_t* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes_arr,
+    const size_t* __restrict__ out_caps, uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
+    hipcompStatus_t* __restrict__ statuses, const size_t part, uint8_t* const smem, const int lane)
+{
+  typedef typename UIntOf<S>::type UT;
+  cgptr comp = to_global(uniform_ptr(comp_ptrs[part]));
+  const size_t comp_bytes64 = uniform((uint64_t)comp_bytes_arr[part]);
+  const bool bad_header = comp == nullptr || comp_bytes64 < kPartMeta;
+  uint32_t type = 0xFFu, code = 0;
+  if (!bad_header) {
+    type = uniform((uint32_t)comp[3]);
     code = uniform((uint32_t)comp[2]) >> 4;
+  }
   const bool undecodable = bad_header || type > 7 || code > 2;
-  constexpr uint32_t kCode = CB == 8192 ? 1u : CB == 16384 ? 2u : 0u;
-  const bool mine = undecodable ? (S == 1 && kCode == 0)
-                                : (code == kCode
-                                   && ((S == 1 && type <= 1) || (S == 2 && (type == 2 || type == 3))
-                                       || (S == 4 && (type == 4 || type == 5)) || (S == 8 && (type == 6 || type == 7))));
-  if (!mine)
-    return;
   auto finish = [&](bool ok, uint32_t bytes) {
     if (lane == 0) {
       actual_bytes[part] = ok ? bytes : 0;
@@ -783,8 +812,13 @@ void launch_decompress(
         != hipSuccess)
       return;
   }
-  k<<<dim3((unsigned)batch), dim3(kWave), lds, stream>>>(comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes,
-                                                         statuses);
+  // as many one-wave workgroups as the chip holds with this much LDS each (handed out in 1280-byte granules)
+  uint32_t per_cu = (160u * 1024u) / ((lds + 1279u) / 1280u * 1280u);
+  if (per_cu > 32)
+    per_cu = 32;
+  const size_t resident = (size_t)num_cus_of_current_device() * per_cu;
+  k<<<dim3((unsigned)(batch < resident ? batch : resident)), dim3(kWave), lds, stream>>>(
+      comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
 }
 
 } // namespace

@@ -1799,6 +1799,8 @@ int current_device()
   return dev;
 }
 
+} // namespace
+
 int num_cus_of_current_device()
 {
   const int dev = current_device();
@@ -1812,6 +1814,8 @@ int num_cus_of_current_device()
   }
   return n;
 }
+
+namespace {
 
 typedef void (*MixKernel)(
     const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t, uint32_t,

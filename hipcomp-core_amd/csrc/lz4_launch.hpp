@@ -9,6 +9,9 @@
 
 namespace hcamd {
 
+// compute units of the calling thread's current device (cached per device; lz4_kernels.hip)
+int num_cus_of_current_device();
+
 // Most waves (= chunks in flight) one compression workgroup of the "mix" shape
 // holds.  Four (one per SIMD): the kernel may then use up to 256 vector
 // registers and keeps clear of the accumulation registers, which its walk uses

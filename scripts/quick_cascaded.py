@@ -1,0 +1,24 @@
+"""Quick Cascaded compress/decompress timing of the built library on one GPU (sorted uint32 columns, 64 KiB partitions):
+   quick_cascaded.py [--parts N] [--chunk-size 4096,8192,16384]"""
+import argparse, importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--parts", type=int, default=100000)
+ap.add_argument("--chunk-size", default="4096")
+ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
+hc = importlib.import_module("hipcomp-core_amd")
+dev = torch.device("cuda:0")
+cols = bench.gen_sorted_columns(a.parts, dev)
+for cb in [int(x) for x in a.chunk_size.split(",")]:
+    job = bench.CodecJob(hc, hc.default_library(), "Cascaded", hc.CascadedOpts(cb, hc.hipcompType.UINT, 2, 1, 1), cols)
+    job.compress(); job.decompress(); torch.cuda.synchronize()
+    job.verify()
+    tc, td = bench.time_phases(job, a.reps)
+    nb, cbytes = job.total, job.compressed_bytes()
+    print(f"cascaded cb={cb} n={job.n}: compress {min(tc):8.3f} ms {nb/min(tc)/1e6:8.1f} GB/s | decompress {min(td):8.3f} ms {nb/min(td)/1e6:8.1f} GB/s | ratio {nb/cbytes:.3f}")
+    del job

@@ -49,8 +49,10 @@ hipcompStatus_t hipcompBatchedLZ4CompressGetMaxOutputChunkSize(
 /* Compress batch_size chunks.  max_uncompressed_chunk_bytes sizes the hash
  * table exactly as the reference does (LZ4CompressionKernels.hip:171), so it
  * takes part in the bit-exact result.  device_temp_ptr: device memory of at
- * least hipcompBatchedLZ4CompressGetTempSize bytes (the first 4 are written).
- * batch_size < 2^31.  (reference LZ4Batch.cpp:189-224) */
+ * least hipcompBatchedLZ4CompressGetTempSize bytes; it holds the call's chunk
+ * counter and, for data that compresses, its hash tables, so ONE temp buffer
+ * serves ONE compress call at a time (calls in flight on different streams
+ * need a buffer each).  batch_size < 2^31.  (reference LZ4Batch.cpp:189-224) */
 hipcompStatus_t hipcompBatchedLZ4CompressAsync(
     const void* const* device_uncompressed_ptrs,
     const size_t* device_uncompressed_bytes,

@@ -75,6 +75,53 @@ def test_sparse_matches_walk_and_rollback(hc, oracle, reflib, cuda, tname, dtype
     assert dec.to_host_chunks() == chunks
 
 
+@pytest.mark.parametrize("tname,dtype,es", [TYPES[0], TYPES[2]])
+def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, tname, dtype, es):
+    """A batch of data that compresses, larger than the LDS-table shape holds in
+    flight: the sampling kernel calls for the "far" shape (hash tables in the
+    temp buffer).  Checked: the counters it left in the temp buffer, that the
+    temp buffer behind them was used, and every chunk's bytes against the
+    oracle (48 distinct chunks, each 32 times: text, the harness's data, runs,
+    sparse repeats, ragged lengths, an empty chunk, and a few chunks of random
+    bytes, which take that kernel's match-less path) and the reference build."""
+    import torch
+    rng = np.random.default_rng(5)
+    base = []
+    for k in range(12):
+        base.append(datagen.text_like(200 + k, 65536 - 97 * k))
+        base.append(datagen.harness_like_int32(300 + k, 16384 - 3 * k).tobytes())
+        base.append(datagen.random_runs_int32(400 + k, 16384 - 5 * k).tobytes())
+    for k in range(6):
+        base.append(datagen.sparse_repeats(500 + k, 65536 - 8 * k, 90 + 40 * k, 5 + k))
+    base += [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in (65536, 65536, 40000, 257)]
+    base += [b"", datagen.text_like(7, 12 * es)]
+    base = [c[: len(c) // es * es] for c in base]
+    assert len(base) == 48
+    chunks = base * 32
+    want = [oracle.lz4_compress(c, es, 65536) for c in base]
+    src = hc.batch.from_host_chunks(chunks, "cuda:0")
+    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
+    dst = hc.batch.alloc_batch(src.n, codec.max_output_chunk_size(65536), src.device)
+    temp = torch.full((codec.compress_temp_size(src.n, 65536),), 0xAB, dtype=torch.uint8, device=src.device)
+    assert codec.compress_async(src, 65536, temp, dst) == 0
+    torch.cuda.synchronize()
+    ticket, repeats, looked = temp[:12].view(torch.int32).cpu().tolist()
+    assert ticket >= src.n and looked > 0 and repeats * 4 > looked     # the sampler's verdict: compressible
+    assert bool((temp[16 : 16 + 4 * 32768] != 0xAB).any().item())     # hash tables of the far shape were written
+    got = dst.to_host_chunks()
+    for i in range(len(chunks)):
+        assert got[i] == want[i % 48], f"chunk {i} {tname}: kernel != oracle"
+    if reflib is not None:
+        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=reflib).compress(src, 65536)
+        torch.cuda.synchronize()
+        refgot = ref.to_host_chunks()
+        for i in range(48):
+            assert refgot[i] == want[i], f"chunk {i} {tname}: oracle != reference"
+    dec, actual, statuses = codec.decompress(dst, 65536)
+    assert statuses.cpu().tolist() == [0] * len(chunks)
+    assert dec.to_host_chunks() == chunks
+
+
 def test_small_tables_many_waves_per_group(hc, oracle, cuda):
     """max_chunk below 16 KiB: smaller hash tables, up to 16 waves (= chunks
     in flight) per workgroup, batch sizes that do not fill the last group."""

@@ -1,7 +1,9 @@
-// hlif.hip -- the high-level interface (include/hipcomp/hipcompManager.hpp, lz4.hpp, hlif.h):
-// one container per buffer, written and read on the device over the batched LZ4 kernels.
+// hlif.hip -- the high-level interface (include/hipcomp/hipcompManager.hpp, lz4.hpp, snappy.hpp,
+// cascaded.hpp, hipcompManagerFactory.hpp, hlif.h): one container per buffer, written and read
+// on the device over the batched kernels of the three codecs.
 //
-// Reference: src/highlevel/{ManagerBase,BatchManager,LZ4Manager}.hpp, the persistent-CTA
+// Reference: src/highlevel/{ManagerBase,BatchManager,LZ4Manager,SnappyManager,CascadedManager}.hpp,
+// hipcompManagerFactory.cpp, the persistent-CTA
 // loop of src/hipcomp_common_deps/hlif_shared.hiph:165-232 (each CTA compresses a chunk into
 // its scratch slot, claims room in the container with an atomic on comp_data_size and copies
 // the chunk there: chunk data in completion order) and :293-345.  Here the chunk list goes
@@ -13,10 +15,16 @@
 #include "lz4_launch.hpp"
 #include "wave_utils.hpp"
 
+#include "hipcomp/cascaded.h"
+#include "hipcomp/cascaded.hpp"
+#include "hipcomp/hipcompManagerFactory.hpp"
 #include "hipcomp/hlif.h"
 #include "hipcomp/lz4.h"
 #include "hipcomp/lz4.hpp"
+#include "hipcomp/snappy.h"
+#include "hipcomp/snappy.hpp"
 
+#include <cstring>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -49,7 +57,13 @@ static_assert(offsetof(CommonHeader, comp_data_size) == 8 && offsetof(CommonHead
                   && offsetof(CommonHeader, uncomp_chunk_size) == 48 && offsetof(CommonHeader, comp_data_offset) == 56,
               "container header layout");
 
-constexpr size_t kFormatHeaderBytes = 4; // LZ4FormatSpecHeader
+// format headers behind the common one (reference include/hipcomp/{lz4,snappy,cascaded}.hpp):
+// LZ4 {hipcompType_t} 4 bytes, Snappy {} 1 byte (an empty struct), Cascaded {options} 24 bytes
+constexpr size_t kMaxFormatHeaderBytes = 24;
+struct FormatHeader
+{
+  uint8_t bytes[kMaxFormatHeaderBytes];
+};
 
 // where the arrays and the chunk data of a container of n chunks start (bytes from its start;
 // the reference aligns the ADDRESS behind the two headers to 8 -- containers are at least
@@ -58,10 +72,10 @@ struct Layout
 {
   size_t offsets, sizes, comp_checksums, decomp_checksums, data;
 };
-inline Layout layout_of(size_t n)
+inline Layout layout_of(size_t n, size_t format_header_bytes)
 {
   Layout l;
-  l.offsets = (sizeof(CommonHeader) + kFormatHeaderBytes + 7) & ~size_t(7);
+  l.offsets = (sizeof(CommonHeader) + format_header_bytes + 7) & ~size_t(7);
   l.sizes = l.offsets + 8 * n;
   l.comp_checksums = l.sizes + 8 * n;
   l.decomp_checksums = l.comp_checksums + 4 * n;
@@ -74,13 +88,13 @@ constexpr int kBlock = 256;
 // ---- compression ------------------------------------------------------------------------
 __global__ void header_kernel(
     uint8_t* container, uint64_t decomp_bytes, uint64_t num_chunks, uint64_t chunk_bytes, uint32_t data_offset,
-    uint32_t data_type, hipcompStatus_t* status)
+    uint8_t format, FormatHeader format_header, uint32_t format_header_bytes, hipcompStatus_t* status)
 {
   CommonHeader* h = reinterpret_cast<CommonHeader*>(container);
   h->magic_number = 0; // reference fill_common_header, hlif_shared.hiph:113-131
   h->major_version = 2;
   h->minor_version = 2;
-  h->format = kLZ4;
+  h->format = format;
   h->comp_data_size = 0;
   h->decomp_data_size = decomp_bytes;
   h->num_chunks = num_chunks;
@@ -91,7 +105,8 @@ __global__ void header_kernel(
   h->include_per_chunk_decomp_buffer_checksums = false;
   h->uncomp_chunk_size = chunk_bytes;
   h->comp_data_offset = data_offset;
-  *reinterpret_cast<uint32_t*>(container + sizeof(CommonHeader)) = data_type;
+  for (uint32_t i = 0; i < format_header_bytes; ++i)
+    container[sizeof(CommonHeader) + i] = format_header.bytes[i];
   if (status)
     *status = hipcompSuccess;
 }
@@ -112,8 +127,10 @@ __global__ void slab_inputs_kernel(
 
 // one workgroup: offsets of the slab's chunks = running total of the container + exclusive
 // scan of their sizes; the running total moves on
+// (`align`: chunk starts are rounded up to it -- 1 for byte codecs; the Cascaded decoder wants
+// its streams aligned like their elements)
 __global__ __launch_bounds__(kBlock) void slab_place_kernel(
-    uint8_t* container, uint64_t sizes_at, uint64_t offsets_at, uint64_t first, uint32_t count)
+    uint8_t* container, uint64_t sizes_at, uint64_t offsets_at, uint64_t first, uint32_t count, uint32_t align)
 {
   __shared__ uint64_t wave_sums[kBlock / 64];
   CommonHeader* h = reinterpret_cast<CommonHeader*>(container);
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void slab_place_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t i0 = 0; i0 < count; i0 += kBlock) {
     const uint32_t i = i0 + threadIdx.x;
-    const uint64_t v = i < count ? sizes[i] : 0;
+    const uint64_t v = i < count ? (sizes[i] + align - 1) / align * align : 0;
     const uint64_t incl = wave_scan_add_u64(v);
     if (lane == 63)
       wave_sums[wave] = incl;
@@ -198,6 +215,210 @@ inline std::shared_ptr<hipcompStatus_t> new_status()
   return std::shared_ptr<hipcompStatus_t>(p, [](hipcompStatus_t* q) { (void)hipHostFree(q); });
 }
 
+// What the three managers share: the container, the slabs, the scratch space.  The codec is
+// a small set of hooks.
+struct Core
+{
+  enum Codec { LZ4, Snappy, Cascaded } codec;
+  size_t chunk_bytes = 0;
+  hipStream_t stream = nullptr;
+  size_t slot_bytes = 0;   // hipcompBatched*CompressGetMaxOutputChunkSize(chunk_bytes), 16-byte multiple
+  uint32_t slab = 0;       // chunks per pass
+  uint8_t format = kLZ4;
+  FormatHeader format_header = {};
+  uint32_t format_header_bytes = 0;
+  uint32_t place_align = 1; // chunk starts in the container
+  // LZ4
+  hipcompType_t lz4_type = HIPCOMP_TYPE_CHAR;
+  int lz4_elem = 1;
+  uint32_t ht_size = 0;
+  // Cascaded
+  hipcompBatchedCascadedOpts_t cascaded_opts = {};
+
+  uint8_t* scratch = nullptr;
+  bool own_scratch = false;
+  CommonHeader* header_host = nullptr; // pinned
+
+  Core(Codec c, size_t chunk, hipStream_t st, int device_id, const char* who) : codec(c), chunk_bytes(chunk), stream(st)
+  {
+    int dev = -1;
+    check(hipGetDevice(&dev), "hipGetDevice");
+    if (dev != device_id)
+      throw std::runtime_error(std::string(who) + ": device_id " + std::to_string(device_id) + " is not the current device");
+    check(hipHostMalloc((void**)&header_host, sizeof(CommonHeader), hipHostMallocDefault), "hipHostMalloc(header)");
+  }
+  ~Core()
+  {
+    if (own_scratch)
+      (void)hipFree(scratch);
+    (void)hipHostFree(header_host);
+  }
+  Core(const Core&) = delete;
+  Core& operator=(const Core&) = delete;
+
+  void finish_init(size_t max_compressed_chunk)
+  {
+    slot_bytes = (max_compressed_chunk + 15) & ~size_t(15);
+    // a slab: about 512 MiB of slots, 256 .. 8192 chunks
+    const size_t n = (size_t(512) << 20) / slot_bytes;
+    slab = (uint32_t)(n < 256 ? 256 : (n > 8192 ? 8192 : n));
+  }
+
+  Layout layout(size_t n) const { return layout_of(n, format_header_bytes); }
+
+  // scratch: chunk lists of a slab, three words for the LZ4 compress kernels, the slots, and
+  // (LZ4) hash tables for the compress kernel's "far" shape, one per chunk of a slab
+  size_t lists_bytes() const { return (size_t)slab * (8 + 8 + 8 + 8 + 8 + 4) + 64; }
+  size_t table_bytes() const { return codec == LZ4 ? (size_t)(ht_size < 8 ? 8 : ht_size) * sizeof(uint16_t) : 0; }
+  size_t scratch_bytes() const { return lists_bytes() + (size_t)slab * slot_bytes + 16 + (size_t)slab * table_bytes(); }
+  uint8_t* ensure_scratch()
+  {
+    if (!scratch) {
+      check(hipMalloc((void**)&scratch, scratch_bytes()), "hipMalloc(scratch)");
+      own_scratch = true;
+    }
+    return scratch;
+  }
+
+  hipcomp::CompressionConfig configure_compression(size_t decomp_buffer_size) const
+  {
+    hipcomp::CompressionConfig c(decomp_buffer_size);
+    c.num_chunks = (decomp_buffer_size + chunk_bytes - 1) / chunk_bytes;
+    c.max_compressed_buffer_size = layout(c.num_chunks).data + c.num_chunks * slot_bytes;
+    return c;
+  }
+
+  void compress(const uint8_t* decomp_buffer, uint8_t* comp_buffer, const hipcomp::CompressionConfig& cfg)
+  {
+    if (reinterpret_cast<uintptr_t>(comp_buffer) & 7)
+      throw std::runtime_error("compress: the container buffer must be 8-byte aligned");
+    uint8_t* const s = ensure_scratch();
+    const size_t n = cfg.num_chunks;
+    const Layout lay = layout(n);
+    const uint8_t** in_ptrs = reinterpret_cast<const uint8_t**>(s);
+    size_t* in_bytes = reinterpret_cast<size_t*>(s + (size_t)slab * 8);
+    uint8_t** out_ptrs = reinterpret_cast<uint8_t**>(s + (size_t)slab * 16);
+    uint32_t* words = reinterpret_cast<uint32_t*>(s + (size_t)slab * 44);
+    uint8_t* slots = s + lists_bytes();
+    uint16_t* tables = reinterpret_cast<uint16_t*>(
+        (reinterpret_cast<uintptr_t>(slots + (size_t)slab * slot_bytes) + 15) & ~uintptr_t(15));
+    header_kernel<<<1, 1, 0, stream>>>(comp_buffer, cfg.uncompressed_buffer_size, n, chunk_bytes, (uint32_t)lay.data,
+                                       format, format_header, format_header_bytes, cfg.get_status());
+    for (size_t first = 0; first < n; first += slab) {
+      const uint32_t count = (uint32_t)(n - first < slab ? n - first : slab);
+      slab_inputs_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, stream>>>(
+          decomp_buffer, cfg.uncompressed_buffer_size, chunk_bytes, first, count, slots, slot_bytes, in_ptrs, in_bytes,
+          out_ptrs);
+      // sizes go straight into the container's size array
+      size_t* sizes = reinterpret_cast<size_t*>(comp_buffer + lay.sizes) + first;
+      switch (codec) {
+      case LZ4:
+        check(lz4_launch_compress(in_ptrs, in_bytes, out_ptrs, sizes, ht_size, count, lz4_elem, words, tables, slab,
+                                  chunk_bytes, lz4_mode_from_environment(), stream),
+              "LZ4Manager::compress");
+        break;
+      case Snappy:
+        if (hipcompBatchedSnappyCompressAsync(reinterpret_cast<const void* const*>(in_ptrs), in_bytes, chunk_bytes, count,
+                                              nullptr, 0, reinterpret_cast<void* const*>(out_ptrs), sizes,
+                                              hipcompBatchedSnappyDefaultOpts, stream)
+            != hipcompSuccess)
+          throw std::runtime_error("SnappyManager::compress: batched compress failed");
+        break;
+      case Cascaded:
+        if (hipcompBatchedCascadedCompressAsync(reinterpret_cast<const void* const*>(in_ptrs), in_bytes, chunk_bytes,
+                                                count, nullptr, 0, reinterpret_cast<void* const*>(out_ptrs), sizes,
+                                                cascaded_opts, stream)
+            != hipcompSuccess)
+          throw std::runtime_error("CascadedManager::compress: batched compress failed");
+        break;
+      }
+      slab_place_kernel<<<1, kBlock, 0, stream>>>(comp_buffer, lay.sizes, lay.offsets, first, count, place_align);
+      slab_gather_kernel<<<(count + 3) / 4, kBlock, 0, stream>>>(comp_buffer, lay.sizes, lay.offsets, lay.data, first,
+                                                                 count, slots, slot_bytes);
+    }
+    check(hipGetLastError(), "compress kernels");
+  }
+
+  const CommonHeader& read_header(const uint8_t* comp_buffer)
+  {
+    check(hipMemcpyAsync(header_host, comp_buffer, sizeof(CommonHeader), hipMemcpyDeviceToHost, stream), "read header");
+    check(hipStreamSynchronize(stream), "read header");
+    return *header_host;
+  }
+
+  hipcomp::DecompressionConfig configure_decompression(const uint8_t* comp_buffer)
+  {
+    hipcomp::DecompressionConfig d;
+    const CommonHeader& h = read_header(comp_buffer);
+    d.decomp_data_size = (size_t)h.decomp_data_size;
+    d.num_chunks = (uint32_t)h.num_chunks;
+    return d;
+  }
+
+  void decompress(uint8_t* decomp_buffer, const uint8_t* comp_buffer, const hipcomp::DecompressionConfig& cfg)
+  {
+    uint8_t* const s = ensure_scratch();
+    const size_t n = cfg.num_chunks;
+    const Layout lay = layout(n);
+    const uint8_t** comp_ptrs = reinterpret_cast<const uint8_t**>(s);
+    size_t* caps = reinterpret_cast<size_t*>(s + (size_t)slab * 8);
+    uint8_t** out_ptrs = reinterpret_cast<uint8_t**>(s + (size_t)slab * 16);
+    size_t* actual = reinterpret_cast<size_t*>(s + (size_t)slab * 24);
+    hipcompStatus_t* statuses = reinterpret_cast<hipcompStatus_t*>(s + (size_t)slab * 40);
+    set_status_kernel<<<1, 1, 0, stream>>>(cfg.get_status(), hipcompSuccess);
+    for (size_t first = 0; first < n; first += slab) {
+      const uint32_t count = (uint32_t)(n - first < slab ? n - first : slab);
+      slab_streams_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, stream>>>(
+          comp_buffer, lay.offsets, decomp_buffer, cfg.decomp_data_size, chunk_bytes, first, count, comp_ptrs, out_ptrs,
+          caps);
+      const size_t* sizes = reinterpret_cast<const size_t*>(comp_buffer + lay.sizes) + first;
+      switch (codec) {
+      case LZ4:
+        lz4_launch_decompress(comp_ptrs, sizes, caps, count, out_ptrs, actual, statuses, true, stream);
+        break;
+      case Snappy:
+        if (hipcompBatchedSnappyDecompressAsync(reinterpret_cast<const void* const*>(comp_ptrs), sizes, caps, actual, count,
+                                                nullptr, 0, reinterpret_cast<void* const*>(out_ptrs), statuses, stream)
+            != hipcompSuccess)
+          throw std::runtime_error("SnappyManager::decompress: batched decompress failed");
+        break;
+      case Cascaded:
+        if (hipcompBatchedCascadedDecompressAsync(reinterpret_cast<const void* const*>(comp_ptrs), sizes, caps, actual,
+                                                  count, nullptr, 0, reinterpret_cast<void* const*>(out_ptrs), statuses,
+                                                  stream)
+            != hipcompSuccess)
+          throw std::runtime_error("CascadedManager::decompress: batched decompress failed");
+        break;
+      }
+      slab_verdict_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, stream>>>(statuses, actual, caps, count,
+                                                                                  cfg.get_status());
+    }
+    check(hipGetLastError(), "decompress kernels");
+  }
+
+  void set_scratch_buffer(uint8_t* new_scratch_buffer)
+  {
+    if (own_scratch)
+      (void)hipFree(scratch);
+    own_scratch = false;
+    scratch = new_scratch_buffer;
+  }
+
+  size_t compressed_output_size(const uint8_t* comp_buffer)
+  {
+    const CommonHeader& h = read_header(comp_buffer);
+    return (size_t)(h.comp_data_size + h.comp_data_offset);
+  }
+};
+
+hipcomp::DecompressionConfig config_of(const hipcomp::CompressionConfig& comp_config)
+{
+  hipcomp::DecompressionConfig d;
+  d.decomp_data_size = comp_config.uncompressed_buffer_size;
+  d.num_chunks = (uint32_t)comp_config.num_chunks;
+  return d;
+}
+
 } // namespace hlif
 } // namespace hcamd
 
@@ -214,176 +435,142 @@ hipcompStatus_t* CompressionConfig::get_status() const { return status.get(); }
 DecompressionConfig::DecompressionConfig() : decomp_data_size(0), num_chunks(0), status(new_status()) {}
 hipcompStatus_t* DecompressionConfig::get_status() const { return status.get(); }
 
+// the eight virtuals of a manager, all on its core
+#define HCAMD_MANAGER_METHODS(M)                                                                                    \
+  M::~M() {}                                                                                                        \
+  CompressionConfig M::configure_compression(const size_t n) { return impl->core.configure_compression(n); }       \
+  void M::compress(const uint8_t* in, uint8_t* out, const CompressionConfig& c) { impl->core.compress(in, out, c); } \
+  DecompressionConfig M::configure_decompression(const uint8_t* comp) { return impl->core.configure_decompression(comp); } \
+  DecompressionConfig M::configure_decompression(const CompressionConfig& c) { return config_of(c); }              \
+  void M::decompress(uint8_t* out, const uint8_t* comp, const DecompressionConfig& c) { impl->core.decompress(out, comp, c); } \
+  void M::set_scratch_buffer(uint8_t* p) { impl->core.set_scratch_buffer(p); }                                      \
+  size_t M::get_required_scratch_buffer_size() { return impl->core.scratch_bytes(); }                               \
+  size_t M::get_compressed_output_size(uint8_t* comp) { return impl->core.compressed_output_size(comp); }
+
 struct LZ4Manager::Impl
 {
-  size_t chunk_bytes;
-  hipcompType_t data_type;
-  int elem;
-  hipStream_t stream;
-  size_t slot_bytes;   // hipcompBatchedLZ4CompressGetMaxOutputChunkSize(chunk_bytes)
-  uint32_t ht_size;
-  uint32_t slab;       // chunks per pass
-  uint8_t* scratch = nullptr;
-  bool own_scratch = false;
-  CommonHeader* header_host = nullptr; // pinned
-
-  // scratch: chunk lists of a slab, three words for the compress kernels, the
-  // slots, hash tables for the compress kernel's "far" shape (one per chunk of a slab)
-  size_t lists_bytes() const { return (size_t)slab * (8 + 8 + 8 + 8 + 8 + 4) + 64; }
-  size_t table_bytes() const { return (size_t)(ht_size < 8 ? 8 : ht_size) * sizeof(uint16_t); }
-  size_t scratch_bytes() const { return lists_bytes() + (size_t)slab * slot_bytes + 16 + (size_t)slab * table_bytes(); }
-  uint8_t* ensure_scratch()
-  {
-    if (!scratch) {
-      check(hipMalloc((void**)&scratch, scratch_bytes()), "hipMalloc(scratch)");
-      own_scratch = true;
-    }
-    return scratch;
-  }
+  Core core;
+  Impl(size_t chunk, hipStream_t st, int dev) : core(Core::LZ4, chunk, st, dev, "LZ4Manager") {}
+};
+struct SnappyManager::Impl
+{
+  Core core;
+  Impl(size_t chunk, hipStream_t st, int dev) : core(Core::Snappy, chunk, st, dev, "SnappyManager") {}
+};
+struct CascadedManager::Impl
+{
+  Core core;
+  Impl(size_t chunk, hipStream_t st, int dev) : core(Core::Cascaded, chunk, st, dev, "CascadedManager") {}
 };
 
 LZ4Manager::LZ4Manager(size_t uncomp_chunk_size, hipcompType_t data_type, hipStream_t user_stream, const int device_id)
-    : impl(new Impl)
 {
-  int dev = -1;
-  check(hipGetDevice(&dev), "hipGetDevice");
-  if (dev != device_id)
-    throw std::runtime_error("LZ4Manager: device_id " + std::to_string(device_id) + " is not the current device");
   if (uncomp_chunk_size == 0 || uncomp_chunk_size > (size_t(1) << 24))
     throw std::runtime_error("LZ4Manager: uncomp_chunk_size must be in [1, 16 MiB]");
   size_t slot = 0;
   if (hipcompBatchedLZ4CompressGetMaxOutputChunkSize(uncomp_chunk_size, hipcompBatchedLZ4Opts_t{data_type}, &slot)
       != hipcompSuccess)
     throw std::runtime_error("LZ4Manager: bad chunk size");
+  int elem = 0;
   switch (data_type) {
-  case HIPCOMP_TYPE_BITS: case HIPCOMP_TYPE_CHAR: case HIPCOMP_TYPE_UCHAR: impl->elem = 1; break;
-  case HIPCOMP_TYPE_SHORT: case HIPCOMP_TYPE_USHORT: impl->elem = 2; break;
-  case HIPCOMP_TYPE_INT: case HIPCOMP_TYPE_UINT: impl->elem = 4; break;
+  case HIPCOMP_TYPE_BITS: case HIPCOMP_TYPE_CHAR: case HIPCOMP_TYPE_UCHAR: elem = 1; break;
+  case HIPCOMP_TYPE_SHORT: case HIPCOMP_TYPE_USHORT: elem = 2; break;
+  case HIPCOMP_TYPE_INT: case HIPCOMP_TYPE_UINT: elem = 4; break;
   default: throw std::runtime_error("LZ4Manager: unsupported data type");
   }
-  impl->chunk_bytes = uncomp_chunk_size;
-  impl->data_type = data_type;
-  impl->stream = user_stream;
-  impl->slot_bytes = (slot + 15) & ~size_t(15);
+  impl.reset(new Impl(uncomp_chunk_size, user_stream, device_id));
+  Core& m = impl->core;
+  m.format = kLZ4;
+  m.format_header_bytes = sizeof(LZ4FormatSpecHeader);
+  const uint32_t t = (uint32_t)data_type;
+  std::memcpy(m.format_header.bytes, &t, sizeof(t));
+  m.lz4_type = data_type;
+  m.lz4_elem = elem;
   size_t p = 1;
   while (p < uncomp_chunk_size)
     p *= 2;
-  impl->ht_size = (uint32_t)(p < 16384 ? p : 16384);
-  // a slab: about 512 MiB of slots, 256 .. 8192 chunks
-  size_t slab = (size_t(512) << 20) / impl->slot_bytes;
-  impl->slab = (uint32_t)(slab < 256 ? 256 : (slab > 8192 ? 8192 : slab));
-  check(hipHostMalloc((void**)&impl->header_host, sizeof(CommonHeader), hipHostMallocDefault), "hipHostMalloc(header)");
+  m.ht_size = (uint32_t)(p < 16384 ? p : 16384);
+  m.finish_init(slot);
 }
+HCAMD_MANAGER_METHODS(LZ4Manager)
 
-LZ4Manager::~LZ4Manager()
+SnappyManager::SnappyManager(size_t uncomp_chunk_size, hipStream_t user_stream, int device_id)
 {
-  if (impl->own_scratch)
-    (void)hipFree(impl->scratch);
-  (void)hipHostFree(impl->header_host);
+  size_t slot = 0;
+  if (uncomp_chunk_size == 0
+      || hipcompBatchedSnappyCompressGetMaxOutputChunkSize(uncomp_chunk_size, hipcompBatchedSnappyDefaultOpts, &slot)
+             != hipcompSuccess)
+    throw std::runtime_error("SnappyManager: bad chunk size");
+  impl.reset(new Impl(uncomp_chunk_size, user_stream, device_id));
+  Core& m = impl->core;
+  m.format = kSnappy;
+  m.format_header_bytes = sizeof(SnappyFormatSpecHeader); // 1: an empty struct
+  m.finish_init(slot);
 }
+HCAMD_MANAGER_METHODS(SnappyManager)
 
-CompressionConfig LZ4Manager::configure_compression(const size_t decomp_buffer_size)
+// Every chunk of the container is one partition of the batched Cascaded codec, cut into the
+// reference's 4096-byte sub-chunks whatever options.chunk_size says (that is the CONTAINER's
+// chunk size here, as in the reference's CascadedManager.hpp:52-57), so the reference reads it.
+CascadedManager::CascadedManager(const hipcompBatchedCascadedOpts_t& options, hipStream_t user_stream, int device_id)
 {
-  CompressionConfig c(decomp_buffer_size);
-  c.num_chunks = (decomp_buffer_size + impl->chunk_bytes - 1) / impl->chunk_bytes;
-  c.max_compressed_buffer_size = layout_of(c.num_chunks).data + c.num_chunks * impl->slot_bytes;
-  return c;
-}
-
-void LZ4Manager::compress(const uint8_t* decomp_buffer, uint8_t* comp_buffer, const CompressionConfig& cfg)
-{
-  Impl& m = *impl;
-  if (reinterpret_cast<uintptr_t>(comp_buffer) & 7)
-    throw std::runtime_error("LZ4Manager::compress: the container buffer must be 8-byte aligned");
-  uint8_t* const s = m.ensure_scratch();
-  const size_t n = cfg.num_chunks;
-  const Layout lay = layout_of(n);
-  const uint8_t** in_ptrs = reinterpret_cast<const uint8_t**>(s);
-  size_t* in_bytes = reinterpret_cast<size_t*>(s + (size_t)m.slab * 8);
-  uint8_t** out_ptrs = reinterpret_cast<uint8_t**>(s + (size_t)m.slab * 16);
-  uint32_t* words = reinterpret_cast<uint32_t*>(s + (size_t)m.slab * 44);
-  uint8_t* slots = s + m.lists_bytes();
-  uint16_t* tables = reinterpret_cast<uint16_t*>(
-      (reinterpret_cast<uintptr_t>(slots + (size_t)m.slab * m.slot_bytes) + 15) & ~uintptr_t(15));
-  header_kernel<<<1, 1, 0, m.stream>>>(comp_buffer, cfg.uncompressed_buffer_size, n, m.chunk_bytes, (uint32_t)lay.data,
-                                       (uint32_t)m.data_type, cfg.get_status());
-  for (size_t first = 0; first < n; first += m.slab) {
-    const uint32_t count = (uint32_t)(n - first < m.slab ? n - first : m.slab);
-    slab_inputs_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, m.stream>>>(
-        decomp_buffer, cfg.uncompressed_buffer_size, m.chunk_bytes, first, count, slots, m.slot_bytes, in_ptrs,
-        in_bytes, out_ptrs);
-    // sizes go straight into the container's size array
-    check(lz4_launch_compress(in_ptrs, in_bytes, out_ptrs, reinterpret_cast<size_t*>(comp_buffer + lay.sizes) + first,
-                              m.ht_size, count, m.elem, words, tables, m.slab, m.chunk_bytes, lz4_mode_from_environment(),
-                              m.stream),
-          "LZ4Manager::compress");
-    slab_place_kernel<<<1, kBlock, 0, m.stream>>>(comp_buffer, lay.sizes, lay.offsets, first, count);
-    slab_gather_kernel<<<(count + 3) / 4, kBlock, 0, m.stream>>>(comp_buffer, lay.sizes, lay.offsets, lay.data, first,
-                                                               count, slots, m.slot_bytes);
+  size_t slot = 0;
+  if (options.chunk_size == 0
+      || hipcompBatchedCascadedCompressGetMaxOutputChunkSize(options.chunk_size, hipcompBatchedCascadedDefaultOpts, &slot)
+             != hipcompSuccess)
+    throw std::runtime_error("CascadedManager: bad chunk size");
+  size_t elem = 0;
+  switch (options.type) {
+  case HIPCOMP_TYPE_CHAR: case HIPCOMP_TYPE_UCHAR: elem = 1; break;
+  case HIPCOMP_TYPE_SHORT: case HIPCOMP_TYPE_USHORT: elem = 2; break;
+  case HIPCOMP_TYPE_INT: case HIPCOMP_TYPE_UINT: elem = 4; break;
+  case HIPCOMP_TYPE_LONGLONG: case HIPCOMP_TYPE_ULONGLONG: elem = 8; break;
+  default: throw std::runtime_error("CascadedManager: unsupported data type");
   }
-  check(hipGetLastError(), "LZ4Manager::compress kernels");
+  if (options.chunk_size % elem)
+    throw std::runtime_error("CascadedManager: chunk_size must be a multiple of the element size");
+  impl.reset(new Impl(options.chunk_size, user_stream, device_id));
+  Core& m = impl->core;
+  m.format = kCascaded;
+  m.format_header_bytes = sizeof(CascadedFormatSpecHeader);
+  static_assert(sizeof(CascadedFormatSpecHeader) <= kMaxFormatHeaderBytes, "format header");
+  std::memcpy(m.format_header.bytes, &options, sizeof(options));
+  m.cascaded_opts = options;
+  m.cascaded_opts.chunk_size = 4096;
+  m.place_align = 8;
+  m.finish_init(slot);
 }
+HCAMD_MANAGER_METHODS(CascadedManager)
 
-DecompressionConfig LZ4Manager::configure_decompression(const uint8_t* comp_buffer)
+// reference hipcompManagerFactory.cpp:44-148 (synchronises the stream, as there)
+std::shared_ptr<hipcompManagerBase> create_manager(const uint8_t* comp_buffer, hipStream_t stream, const int device_id)
 {
-  Impl& m = *impl;
-  DecompressionConfig d;
-  check(hipMemcpyAsync(m.header_host, comp_buffer, sizeof(CommonHeader), hipMemcpyDeviceToHost, m.stream), "read header");
-  check(hipStreamSynchronize(m.stream), "read header");
-  d.decomp_data_size = (size_t)m.header_host->decomp_data_size;
-  d.num_chunks = (uint32_t)m.header_host->num_chunks;
-  return d;
-}
-
-DecompressionConfig LZ4Manager::configure_decompression(const CompressionConfig& comp_config)
-{
-  DecompressionConfig d;
-  d.decomp_data_size = comp_config.uncompressed_buffer_size;
-  d.num_chunks = (uint32_t)comp_config.num_chunks;
-  return d;
-}
-
-void LZ4Manager::decompress(uint8_t* decomp_buffer, const uint8_t* comp_buffer, const DecompressionConfig& cfg)
-{
-  Impl& m = *impl;
-  uint8_t* const s = m.ensure_scratch();
-  const size_t n = cfg.num_chunks;
-  const Layout lay = layout_of(n);
-  const uint8_t** comp_ptrs = reinterpret_cast<const uint8_t**>(s);
-  size_t* caps = reinterpret_cast<size_t*>(s + (size_t)m.slab * 8);
-  uint8_t** out_ptrs = reinterpret_cast<uint8_t**>(s + (size_t)m.slab * 16);
-  size_t* actual = reinterpret_cast<size_t*>(s + (size_t)m.slab * 24);
-  hipcompStatus_t* statuses = reinterpret_cast<hipcompStatus_t*>(s + (size_t)m.slab * 40);
-  set_status_kernel<<<1, 1, 0, m.stream>>>(cfg.get_status(), hipcompSuccess);
-  for (size_t first = 0; first < n; first += m.slab) {
-    const uint32_t count = (uint32_t)(n - first < m.slab ? n - first : m.slab);
-    slab_streams_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, m.stream>>>(
-        comp_buffer, lay.offsets, decomp_buffer, cfg.decomp_data_size, m.chunk_bytes, first, count, comp_ptrs,
-        out_ptrs, caps);
-    lz4_launch_decompress(comp_ptrs, reinterpret_cast<const size_t*>(comp_buffer + lay.sizes) + first, caps, count,
-                          out_ptrs, actual, statuses, true, m.stream);
-    slab_verdict_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, m.stream>>>(statuses, actual, caps, count,
-                                                                                cfg.get_status());
+  struct Heads
+  {
+    CommonHeader common;
+    FormatHeader format;
+  } heads;
+  check(hipMemcpyAsync(&heads, comp_buffer, sizeof(heads), hipMemcpyDeviceToHost, stream), "create_manager: read headers");
+  check(hipStreamSynchronize(stream), "create_manager: read headers");
+  switch (heads.common.format) {
+  case kLZ4: {
+    uint32_t t;
+    std::memcpy(&t, heads.format.bytes, sizeof(t));
+    return std::make_shared<LZ4Manager>((size_t)heads.common.uncomp_chunk_size, (hipcompType_t)t, stream, device_id);
   }
-  check(hipGetLastError(), "LZ4Manager::decompress kernels");
-}
-
-void LZ4Manager::set_scratch_buffer(uint8_t* new_scratch_buffer)
-{
-  if (impl->own_scratch)
-    (void)hipFree(impl->scratch);
-  impl->own_scratch = false;
-  impl->scratch = new_scratch_buffer;
-}
-
-size_t LZ4Manager::get_required_scratch_buffer_size() { return impl->scratch_bytes(); }
-
-size_t LZ4Manager::get_compressed_output_size(uint8_t* comp_buffer)
-{
-  Impl& m = *impl;
-  check(hipMemcpyAsync(m.header_host, comp_buffer, sizeof(CommonHeader), hipMemcpyDeviceToHost, m.stream), "read header");
-  check(hipStreamSynchronize(m.stream), "read header");
-  return (size_t)(m.header_host->comp_data_size + m.header_host->comp_data_offset);
+  case kSnappy:
+    return std::make_shared<SnappyManager>((size_t)heads.common.uncomp_chunk_size, stream, device_id);
+  case kCascaded: {
+    hipcompBatchedCascadedOpts_t o;
+    std::memcpy(&o, heads.format.bytes, sizeof(o));
+    if (o.chunk_size != heads.common.uncomp_chunk_size)
+      throw std::runtime_error("create_manager: Cascaded options do not match the container's chunk size");
+    return std::make_shared<CascadedManager>(o, stream, device_id);
+  }
+  default:
+    throw std::runtime_error("create_manager: format " + std::to_string((int)heads.common.format)
+                             + " is not supported (LZ4, Snappy and Cascaded are)");
+  }
 }
 
 } // namespace hipcomp
@@ -391,7 +578,7 @@ size_t LZ4Manager::get_compressed_output_size(uint8_t* comp_buffer)
 // ---- C binding -----------------------------------------------------------------------------
 struct hipcompHlifManager
 {
-  hipcomp::LZ4Manager* lz4 = nullptr;
+  std::shared_ptr<hipcomp::hipcompManagerBase> lz4; // (any of the managers)
   hipStream_t stream = nullptr;
   std::unique_ptr<hipcomp::CompressionConfig> last_comp;
   std::unique_ptr<hipcomp::DecompressionConfig> last_decomp;
@@ -422,7 +609,52 @@ hipcompStatus_t hipcompHlifLZ4ManagerCreate(
     int dev = 0;
     hcamd::hlif::check(hipGetDevice(&dev), "hipGetDevice");
     std::unique_ptr<hipcompHlifManager> h(new hipcompHlifManager);
-    h->lz4 = new hipcomp::LZ4Manager(uncomp_chunk_size, data_type, stream, dev);
+    h->lz4 = std::make_shared<hipcomp::LZ4Manager>(uncomp_chunk_size, data_type, stream, dev);
+    h->stream = stream;
+    *manager = h.release();
+  });
+}
+
+hipcompStatus_t hipcompHlifSnappyManagerCreate(size_t uncomp_chunk_size, hipStream_t stream, hipcompHlifManager_t** manager)
+{
+  static const char* fn = "hipcompHlifSnappyManagerCreate()";
+  HCAMD_REQUIRE_NOT_NULL(fn, manager);
+  return guarded(fn, [&] {
+    int dev = 0;
+    hcamd::hlif::check(hipGetDevice(&dev), "hipGetDevice");
+    std::unique_ptr<hipcompHlifManager> h(new hipcompHlifManager);
+    h->lz4 = std::make_shared<hipcomp::SnappyManager>(uncomp_chunk_size, stream, dev);
+    h->stream = stream;
+    *manager = h.release();
+  });
+}
+
+hipcompStatus_t hipcompHlifCascadedManagerCreate(
+    hipcompBatchedCascadedOpts_t options, hipStream_t stream, hipcompHlifManager_t** manager)
+{
+  static const char* fn = "hipcompHlifCascadedManagerCreate()";
+  HCAMD_REQUIRE_NOT_NULL(fn, manager);
+  return guarded(fn, [&] {
+    int dev = 0;
+    hcamd::hlif::check(hipGetDevice(&dev), "hipGetDevice");
+    std::unique_ptr<hipcompHlifManager> h(new hipcompHlifManager);
+    h->lz4 = std::make_shared<hipcomp::CascadedManager>(options, stream, dev);
+    h->stream = stream;
+    *manager = h.release();
+  });
+}
+
+hipcompStatus_t hipcompHlifManagerCreateFromContainer(
+    const void* device_container, hipStream_t stream, hipcompHlifManager_t** manager)
+{
+  static const char* fn = "hipcompHlifManagerCreateFromContainer()";
+  HCAMD_REQUIRE_NOT_NULL(fn, manager);
+  HCAMD_REQUIRE_NOT_NULL(fn, device_container);
+  return guarded(fn, [&] {
+    int dev = 0;
+    hcamd::hlif::check(hipGetDevice(&dev), "hipGetDevice");
+    std::unique_ptr<hipcompHlifManager> h(new hipcompHlifManager);
+    h->lz4 = hipcomp::create_manager(static_cast<const uint8_t*>(device_container), stream, dev);
     h->stream = stream;
     *manager = h.release();
   });
@@ -430,10 +662,7 @@ hipcompStatus_t hipcompHlifLZ4ManagerCreate(
 
 hipcompStatus_t hipcompHlifManagerDestroy(hipcompHlifManager_t* manager)
 {
-  if (manager) {
-    delete manager->lz4;
-    delete manager;
-  }
+  delete manager;
   return hipcompSuccess;
 }
 

@@ -1,12 +1,13 @@
 /*
- * hipcomp/hlif.h -- C binding of the high-level interface's LZ4 manager
- * (hipcomp/lz4.hpp; the reference offers it in C++ only).  A manager is an opaque handle;
- * every call returns a status instead of throwing.
+ * hipcomp/hlif.h -- C binding of the high-level interface's managers (hipcomp/lz4.hpp,
+ * snappy.hpp, cascaded.hpp, hipcompManagerFactory.hpp; the reference offers them in C++
+ * only).  A manager is an opaque handle; every call returns a status instead of throwing.
  */
 #ifndef HIPCOMP_HLIF_H
 #define HIPCOMP_HLIF_H
 
 #include "hipcomp.h"
+#include "hipcomp/cascaded.h"
 
 #include <hip/hip_runtime_api.h>
 #include <stddef.h>
@@ -20,6 +21,14 @@ typedef struct hipcompHlifManager hipcompHlifManager_t;
 
 hipcompStatus_t hipcompHlifLZ4ManagerCreate(
     size_t uncomp_chunk_size, hipcompType_t data_type, hipStream_t stream, hipcompHlifManager_t** manager);
+hipcompStatus_t hipcompHlifSnappyManagerCreate(
+    size_t uncomp_chunk_size, hipStream_t stream, hipcompHlifManager_t** manager);
+/* options.chunk_size is the chunk size of the container */
+hipcompStatus_t hipcompHlifCascadedManagerCreate(
+    hipcompBatchedCascadedOpts_t options, hipStream_t stream, hipcompHlifManager_t** manager);
+/* the manager that reads the container at device_container (synchronises the stream) */
+hipcompStatus_t hipcompHlifManagerCreateFromContainer(
+    const void* device_container, hipStream_t stream, hipcompHlifManager_t** manager);
 hipcompStatus_t hipcompHlifManagerDestroy(hipcompHlifManager_t* manager);
 
 /* *max_compressed_bytes: size to give the container buffer; *num_chunks: chunks it will hold */

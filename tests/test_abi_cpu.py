@@ -46,12 +46,14 @@ def test_library_exports_exactly_the_declared_abi(hc):
     assert len(prims) == 7 and prims <= exported
     # the C++ classes of hipcomp/primitives.hpp (reference src/{RunLengthEncodeGPU,DeltaGPU,BitPackGPU}.h)
     classes = {e.split("(")[0] for e in exported if e.startswith("hipcomp::")}
-    hlif_classes = {c for c in classes if c.split("::")[1] in ("LZ4Manager", "CompressionConfig", "DecompressionConfig")}
-    assert {"hipcomp::LZ4Manager::compress", "hipcomp::LZ4Manager::decompress", "hipcomp::LZ4Manager::LZ4Manager",
-            "hipcomp::LZ4Manager::configure_compression", "hipcomp::LZ4Manager::configure_decompression",
-            "hipcomp::LZ4Manager::get_compressed_output_size", "hipcomp::LZ4Manager::set_scratch_buffer",
-            "hipcomp::LZ4Manager::get_required_scratch_buffer_size", "hipcomp::CompressionConfig::get_status",
-            "hipcomp::DecompressionConfig::get_status"} <= hlif_classes
+    managers = ("LZ4Manager", "SnappyManager", "CascadedManager")
+    hlif_classes = {c for c in classes if c.split("::")[1] in managers + ("CompressionConfig", "DecompressionConfig", "create_manager")}
+    for m in managers:                                    # the reference's manager surface, per format
+        assert {f"hipcomp::{m}::{f}" for f in (m, "compress", "decompress", "configure_compression", "configure_decompression",
+                                                 "get_compressed_output_size", "set_scratch_buffer",
+                                                 "get_required_scratch_buffer_size")} <= hlif_classes
+    assert {"hipcomp::CompressionConfig::get_status", "hipcomp::DecompressionConfig::get_status",
+            "hipcomp::create_manager"} <= hlif_classes
     classes -= hlif_classes
     assert classes == {"hipcomp::RunLengthEncodeGPU::compress", "hipcomp::RunLengthEncodeGPU::compressDownstream",
                        "hipcomp::RunLengthEncodeGPU::requiredWorkspaceSize", "hipcomp::DeltaGPU::compress",
@@ -60,7 +62,7 @@ def test_library_exports_exactly_the_declared_abi(hc):
     interop = _declared_interop()
     assert len(interop) == 3 and interop <= exported
     hlif = _declared_hlif()
-    assert len(hlif) == 9 and hlif <= exported
+    assert len(hlif) == 12 and hlif <= exported
     others = {e for e in exported if not e.startswith("hipcomp::") and not e.startswith(("vtable for", "typeinfo"))}
     assert others <= declared | prims | interop | hlif, sorted(others - declared - prims - interop - hlif)
 

@@ -1,4 +1,5 @@
-"""The high-level interface's LZ4 manager (hipcomp/lz4.hpp via its C binding hipcomp/hlif.h):
+"""The high-level interface's managers (hipcomp/{lz4,snappy,cascaded}.hpp and the factory, via
+the C binding hipcomp/hlif.h):
 container layout (reference src/hipcomp_common_deps/hlif_shared_types.hpp:68-84,
 src/highlevel/BatchManager.hpp:108-112), chunks = the batched API's streams = the oracle's,
 round trips, and both directions against the REFERENCE's own manager (oracle/_ref/hlif_ref_tool,
@@ -23,11 +24,25 @@ def _lib(hc):
     return ctypes.CDLL(hc.default_library().path)
 
 
+class CascadedOpts(ctypes.Structure):
+    _fields_ = [("chunk_size", c_size_t), ("type", c_int), ("num_RLEs", c_int), ("num_deltas", c_int), ("use_bp", c_int)]
+
+
 class Manager:
-    def __init__(self, L, chunk, dtype):
+    def __init__(self, L, chunk=None, dtype=None, snappy=False, cascaded=None, container=None, cuda=None):
         self.L = L
         self.h = c_void_p()
-        assert L.hipcompHlifLZ4ManagerCreate(c_size_t(chunk), c_int(dtype), None, ctypes.byref(self.h)) == 0
+        if container is not None:                         # the factory: manager from a container on the device
+            import torch
+            self.keep = torch.from_numpy(np.frombuffer(container, dtype=np.uint8).copy()).to(cuda)
+            assert L.hipcompHlifManagerCreateFromContainer(c_void_p(self.keep.data_ptr()), None, ctypes.byref(self.h)) == 0
+        elif cascaded is not None:
+            L.hipcompHlifCascadedManagerCreate.argtypes = [CascadedOpts, c_void_p, c_void_p]
+            assert L.hipcompHlifCascadedManagerCreate(cascaded, None, ctypes.byref(self.h)) == 0
+        elif snappy:
+            assert L.hipcompHlifSnappyManagerCreate(c_size_t(chunk), None, ctypes.byref(self.h)) == 0
+        else:
+            assert L.hipcompHlifLZ4ManagerCreate(c_size_t(chunk), c_int(dtype), None, ctypes.byref(self.h)) == 0
 
     def close(self):
         self.L.hipcompHlifManagerDestroy(self.h)
@@ -135,7 +150,7 @@ def test_containers_interchange_with_the_reference_manager(hc, cuda, tmp_path, c
     assert (tmp_path / "ours.out").read_bytes() == data
     # reference -> ours
     (tmp_path / "in.bin").write_bytes(data)
-    r = subprocess.run([REF_TOOL, "compress", str(chunk), str(dtype), str(tmp_path / "in.bin"), str(tmp_path / "ref.bin")],
+    r = subprocess.run([REF_TOOL, "compress", "lz4", str(chunk), str(dtype), str(tmp_path / "in.bin"), str(tmp_path / "ref.bin")],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     ref_cont = (tmp_path / "ref.bin").read_bytes()
@@ -147,3 +162,113 @@ def test_containers_interchange_with_the_reference_manager(hc, cuda, tmp_path, c
         assert (cont[a["data_off"] + a["offs"][i]: a["data_off"] + a["offs"][i] + a["sizes"][i]]
                 == ref_cont[b["data_off"] + b["offs"][i]: b["data_off"] + b["offs"][i] + b["sizes"][i]])
     m.close()
+
+
+def _head(container: bytes, fh_bytes: int):
+    """common header + arrays of a container whose format header has fh_bytes bytes"""
+    magic, major, minor, fmt = struct.unpack_from("<IBBB", container, 0)
+    comp_size, decomp_size, n = struct.unpack_from("<QQQ", container, 8)
+    chunk, = struct.unpack_from("<Q", container, 48)
+    data_off, = struct.unpack_from("<I", container, 56)
+    at = (64 + fh_bytes + 7) // 8 * 8
+    offs = struct.unpack_from(f"<{n}Q", container, at)
+    sizes = struct.unpack_from(f"<{n}Q", container, at + 8 * n)
+    return dict(version=(major, minor), format=fmt, comp_size=comp_size, decomp_size=decomp_size, n=n, chunk=chunk,
+                data_off=data_off, arrays_at=at, offs=offs, sizes=sizes)
+
+
+def _ref(args, tmp_path):
+    r = subprocess.run([REF_TOOL] + [str(a) for a in args], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("chunk", [65536, 5000])
+def test_snappy_manager(hc, oracle, cuda, tmp_path, chunk):
+    """Snappy container: format 1, one byte of format header, chunks = the batched Snappy
+    streams (= the oracle's); round trip; the factory; both directions against the reference."""
+    L = _lib(hc)
+    m = Manager(L, chunk, snappy=True)
+    data = datagen.tpch_lineitem_text(3, 400000) + bytes(np.random.default_rng(1).integers(0, 256, 70001, dtype=np.uint8))
+    for d in (data, b"", b"xyz"):
+        cont, nc = m.compress(d, cuda)
+        h = _head(cont, 1)
+        assert (h["version"], h["format"], h["chunk"], h["decomp_size"], h["n"]) == ((2, 2), 1, chunk, len(d), nc)
+        assert h["data_off"] == 72 + 24 * nc and len(cont) == h["data_off"] + h["comp_size"]
+        for i in range(nc):
+            blob = cont[h["data_off"] + h["offs"][i]: h["data_off"] + h["offs"][i] + h["sizes"][i]]
+            assert blob == oracle.snappy_compress(d[i * chunk:(i + 1) * chunk])
+        st, back = m.decompress(cont, cuda)
+        assert st == 0 and back == d
+    cont, _ = m.compress(data, cuda)
+    f = Manager(L, container=cont, cuda=cuda)                 # factory picks the Snappy manager
+    st, back = f.decompress(cont, cuda)
+    assert st == 0 and back == data
+    f.close()
+    if os.path.exists(REF_TOOL):
+        (tmp_path / "ours.bin").write_bytes(cont)
+        _ref(["decompress", tmp_path / "ours.bin", tmp_path / "ours.out"], tmp_path)
+        assert (tmp_path / "ours.out").read_bytes() == data
+        (tmp_path / "in.bin").write_bytes(data)
+        _ref(["compress", "snappy", chunk, tmp_path / "in.bin", tmp_path / "ref.bin"], tmp_path)
+        ref_cont = (tmp_path / "ref.bin").read_bytes()
+        st, back = m.decompress(ref_cont, cuda)
+        assert st == 0 and back == data
+        b = _head(ref_cont, 1)
+        assert b["sizes"] == _head(cont, 1)["sizes"]          # chunk for chunk the same streams
+    m.close()
+
+
+@pytest.mark.parametrize("chunk,tname,t,es,r,dl,bp", [(4096, "UINT", 5, 4, 2, 1, 1), (4096, "UCHAR", 1, 1, 1, 0, 1),
+                                                      (16384, "USHORT", 3, 2, 1, 1, 1), (8192, "ULONGLONG", 7, 8, 2, 1, 1)])
+def test_cascaded_manager(hc, cuda, tmp_path, chunk, tname, t, es, r, dl, bp):
+    """Cascaded container: format 4, the options as format header, every chunk one partition of
+    the batched codec (4096-byte sub-chunks); round trip; the factory; the reference."""
+    L = _lib(hc)
+    opts = CascadedOpts(chunk, t, r, dl, bp)
+    m = Manager(L, cascaded=opts)
+    col = datagen.sorted_column(11, 300000 // es)
+    data = (col.astype({1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[es])).tobytes()
+    data += bytes(np.random.default_rng(2).integers(0, 256, 5000 * es, dtype=np.uint8))
+    for d in (data, b"", data[: 3 * es]):
+        cont, nc = m.compress(d, cuda)
+        h = _head(cont, 24)
+        assert (h["version"], h["format"], h["chunk"], h["decomp_size"], h["n"]) == ((2, 2), 4, chunk, len(d), nc)
+        assert struct.unpack_from("<Qiiii", cont, 64) == (chunk, t, r, dl, bp)
+        assert h["arrays_at"] == 88 and h["data_off"] == 88 + 24 * nc and len(cont) == h["data_off"] + h["comp_size"]
+        assert all(o % 8 == 0 for o in h["offs"])
+        st, back = m.decompress(cont, cuda)
+        assert st == 0 and back == d
+    cont, _ = m.compress(data, cuda)
+    assert es != 4 or len(cont) < len(data)                   # (the column survives the narrower types only in part)
+    f = Manager(L, container=cont, cuda=cuda)
+    st, back = f.decompress(cont, cuda)
+    assert st == 0 and back == data
+    f.close()
+    if os.path.exists(REF_TOOL):
+        (tmp_path / "ours.bin").write_bytes(cont)
+        _ref(["decompress", tmp_path / "ours.bin", tmp_path / "ours.out"], tmp_path)
+        assert (tmp_path / "ours.out").read_bytes() == data
+        (tmp_path / "in.bin").write_bytes(data)
+        _ref(["compress", "cascaded", chunk, t, r, dl, bp, tmp_path / "in.bin", tmp_path / "ref.bin"], tmp_path)
+        ref_cont = (tmp_path / "ref.bin").read_bytes()
+        st, back = m.decompress(ref_cont, cuda)
+        assert st == 0 and back == data
+    m.close()
+
+
+def test_factory_picks_the_lz4_manager_and_refuses_other_formats(hc, cuda):
+    L = _lib(hc)
+    m = Manager(L, 8192, 4)
+    data = datagen.harness_like_int32(8, 30000).tobytes()
+    cont, _ = m.compress(data, cuda)
+    f = Manager(L, container=cont, cuda=cuda)
+    st, back = f.decompress(cont, cuda)
+    assert st == 0 and back == data
+    f.close()
+    m.close()
+    import torch
+    bad = bytearray(cont)
+    bad[6] = 3                                                # GDeflate: a closed format
+    t = torch.from_numpy(np.frombuffer(bytes(bad), dtype=np.uint8).copy()).to(cuda)
+    h = c_void_p()
+    assert L.hipcompHlifManagerCreateFromContainer(c_void_p(t.data_ptr()), None, ctypes.byref(h)) == 10

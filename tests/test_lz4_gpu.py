@@ -3,6 +3,7 @@ oracle and vs the reference's own build (oracle/_ref, when present), round
 trips, the reference harness's batches and its error-path checks
 (reference tests/test_batch_c_api.h:225-790)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -106,8 +107,10 @@ def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, tname
     assert codec.compress_async(src, 65536, temp, dst) == 0
     torch.cuda.synchronize()
     ticket, repeats, looked = temp[:12].view(torch.int32).cpu().tolist()
-    assert ticket >= src.n and looked > 0 and repeats * 4 > looked     # the sampler's verdict: compressible
-    assert bool((temp[16 : 16 + 4 * 32768] != 0xAB).any().item())     # hash tables of the far shape were written
+    assert ticket >= src.n
+    if os.environ.get("HIPCOMP_LZ4_SHAPE", "auto") == "auto":          # (a forced shape skips the sampling kernel)
+        assert looked > 0 and repeats * 4 > looked                     # the sampler's verdict: compressible
+        assert bool((temp[16 : 16 + 4 * 32768] != 0xAB).any().item())  # hash tables of the far shape were written
     got = dst.to_host_chunks()
     for i in range(len(chunks)):
         assert got[i] == want[i % 48], f"chunk {i} {tname}: kernel != oracle"

@@ -775,25 +775,39 @@ __device__ __forceinline__ int walk_decide(
                  "v"(cand_word[3]), "v"(B.word[3]), "v"(B.at[3]), "v"(B.pos[3]),
                  "v"((uint32_t)B.rb[0]), "v"((uint32_t)B.rb[1]), "v"((uint32_t)B.rb[2]), "v"((uint32_t)B.rb[3])
                : "vcc");
-  odd = (odd | B.sharer) & W.counts;
   // the one trip to the scalar unit of the block
-  const uint64_t suspects = wave_ballot(miss == 0) | wave_ballot(odd != 0);
-  if (__builtin_expect(suspects == 0, 1))
+  const uint64_t hits = wave_ballot(miss == 0);
+  const uint64_t odds = wave_ballot(((odd | B.sharer) & W.counts) != 0);
+  if (__builtin_expect((hits | odds) == 0, 1))
     return G;
+  // Something to look at -- in about a third of the blocks of incompressible
+  // data, because two of a window's 61 lanes hash to one slot (11 % of the
+  // windows), so this path is kept short: only what the flags call for.
+  // (All the lane masks first -- independent vector compares, one trip to the
+  // scalar side for the lot -- then the loops.)
   const uint64_t validc = W.validc;
+  const bool with31 = wave_ballot((B.sharer & W.counts) != 0) != 0; // a lane shares window lane 31's slot (rare)
+  // a lane that does not read back its own insert shares its slot; window lane
+  // 31 never stores (for it the test says nothing), it takes part iff another
+  // lane is in its slot
+  uint64_t U[G];
+#pragma unroll
+  for (int k = 0; k < G; ++k)
+    U[k] = wave_ballot(((B.rb[k] ^ B.pos[k]) & 0xFFFFu) != 0) & validc & ~kSigmaLane31;
+  if (__builtin_expect(with31, 0)) {
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+      if (wave_ballot(B.hpos[k] == read_lane(B.hpos[k], 63)) & validc & ~kSigmaLane31)
+        U[k] |= kSigmaLane31;
+  }
 #pragma unroll
   for (int k = 0; k < G; ++k) {
-    if (wave_ballot(cand_word[k] == B.word[k] && B.at[k] != B.pos[k]) & validc)
+    if (hits != 0 && (wave_ballot(cand_word[k] == B.word[k] && B.at[k] != B.pos[k]) & validc))
       return k;
-    // a lane that does not read back its own insert shares its slot; window
-    // lane 31 never stores (for it the test says nothing), it takes part iff
-    // another lane is in its slot
-    uint64_t U = wave_ballot((uint32_t)B.rb[k] != (B.pos[k] & 0xFFFFu)) & validc & ~kSigmaLane31;
-    if (wave_ballot(B.hpos[k] == read_lane(B.hpos[k], 63)) & validc & ~kSigmaLane31)
-      U |= kSigmaLane31;
-    while (U) { // exact: does a slot sharer hold the word of another lane?
-      const int u = __builtin_ctzll(U);
-      U &= U - 1;
+    uint64_t u_k = U[k];
+    while (u_k) { // exact: does a slot sharer hold the word of another lane?
+      const int u = __builtin_ctzll(u_k);
+      u_k &= u_k - 1;
       const uint32_t v = read_lane(B.word[k], u);
       const uint64_t m = wave_ballot(B.word[k] == v) & validc;
       if (m & (m - 1))

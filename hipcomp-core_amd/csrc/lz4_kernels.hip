@@ -800,20 +800,28 @@ __device__ __forceinline__ int walk_decide(
       if (wave_ballot(B.hpos[k] == read_lane(B.hpos[k], 63)) & validc & ~kSigmaLane31)
         U[k] |= kSigmaLane31;
   }
+  // exact: does a slot sharer hold the word of another lane?
+#define HC_SHARERS_OF(k)                                             \
+  for (uint64_t u_k = U[k]; u_k != 0; u_k &= u_k - 1) {              \
+    const uint32_t v = read_lane(B.word[k], __builtin_ctzll(u_k));   \
+    const uint64_t m = wave_ballot(B.word[k] == v) & validc;         \
+    if (m & (m - 1))                                                 \
+      return k;                                                      \
+  }
+  if (__builtin_expect(hits == 0, 1)) { // the usual case written out: no candidate holds its lane's word
+    HC_SHARERS_OF(0)
+    HC_SHARERS_OF(1)
+    HC_SHARERS_OF(2)
+    HC_SHARERS_OF(3)
+    return G;
+  }
 #pragma unroll
   for (int k = 0; k < G; ++k) {
-    if (hits != 0 && (wave_ballot(cand_word[k] == B.word[k] && B.at[k] != B.pos[k]) & validc))
+    if (wave_ballot(cand_word[k] == B.word[k] && B.at[k] != B.pos[k]) & validc)
       return k;
-    uint64_t u_k = U[k];
-    while (u_k) { // exact: does a slot sharer hold the word of another lane?
-      const int u = __builtin_ctzll(u_k);
-      u_k &= u_k - 1;
-      const uint32_t v = read_lane(B.word[k], u);
-      const uint64_t m = wave_ballot(B.word[k] == v) & validc;
-      if (m & (m - 1))
-        return k;
-    }
+    HC_SHARERS_OF(k)
   }
+#undef HC_SHARERS_OF
   return G;
 }
 

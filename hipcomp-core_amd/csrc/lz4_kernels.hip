@@ -1060,6 +1060,9 @@ __device__ __forceinline__ void compress_wave(
   WL.sig = sig < (uint32_t)NVMAX ? sig : 31u;
   WL.never = (NVMAX == 64 && sig == 63u) ? 0x10000u : 0u;
   WL.counts = (sig < (uint32_t)NVMAX && sig != 31u) ? ~0u : 0u;
+  // (a bit mask to the compiler, not a condition: it would turn every `& counts`
+  // into a scalar lane-mask AND and rebuild a vector value from it for the ballot)
+  asm volatile("" : "+v"(WL.counts));
   // where the stores of lanes that must not store go: an LDS address beyond
   // all a workgroup can own -- the hardware drops them (tests/test_hw_probes.py)
   // and the tables can fill the 160 KiB to the last byte.  (As vector

@@ -944,12 +944,38 @@ __device__ __forceinline__ uint32_t walk_run(
   // (the first two steps have fewer loads behind them and nothing to decide yet)
   HC_WALK_STEP(B, A, C, 1, 2 * G, false, false)
   HC_WALK_STEP(C, B, A, 2, 3 * G, true, true)
+#undef HC_WALK_STEP
+  // The steady state.  It is left for the drain through ONE exit behind the
+  // loop (`rot` = the step that did not run): with the drain inside the loop
+  // the compiler joined its path with the loop's and paid for the join with 21
+  // register copies per step on the loop's path.
+#define HC_WALK_STEP(CUR, P1, P2, RC)                                                       \
+  {                                                                                         \
+    const uint32_t dn = da + (uint32_t)(G * NVMAX);                                         \
+    if ((int)(L - dn - LVM) < G * NVMAX) {                                                  \
+      rot = RC;                                                                             \
+      break;                                                                                \
+    }                                                                                       \
+    const int j = walk_step<S, G, RC, 4 * G, true, SMALL>(CUR, P1, P2, T, in, dn, WL,       \
+                                                          hmask, last_word);                \
+    if (j < G) {                                                                            \
+      match = true;                                                                         \
+      return da - (uint32_t)(G * NVMAX) + (uint32_t)(j * NVMAX);                            \
+    }                                                                                       \
+    da = dn;                                                                                \
+  }
+  int rot;
   for (;;) {
-    HC_WALK_STEP(A, C, B, 0, 4 * G, true, true)
-    HC_WALK_STEP(B, A, C, 1, 4 * G, true, true)
-    HC_WALK_STEP(C, B, A, 2, 4 * G, true, true)
+    HC_WALK_STEP(A, C, B, 0)
+    HC_WALK_STEP(B, A, C, 1)
+    HC_WALK_STEP(C, B, A, 2)
   }
 #undef HC_WALK_STEP
+  if (rot == 0)
+    return walk_drain<S, G, 2, SMALL>(C, B, true, T, in, da, WL, match);
+  if (rot == 1)
+    return walk_drain<S, G, 0, SMALL>(A, C, true, T, in, da, WL, match);
+  return walk_drain<S, G, 1, SMALL>(B, A, true, T, in, da, WL, match);
 }
 
 // The sequence that ends with the match D found in the window at element wd

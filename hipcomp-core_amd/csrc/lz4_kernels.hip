@@ -956,21 +956,25 @@ __device__ __forceinline__ uint32_t walk_run(
       rot = RC;                                                                             \
       break;                                                                                \
     }                                                                                       \
-    const int j = walk_step<S, G, RC, 4 * G, true, SMALL>(CUR, P1, P2, T, in, dn, WL,       \
-                                                          hmask, last_word);                \
-    if (j < G) {                                                                            \
-      match = true;                                                                         \
-      return da - (uint32_t)(G * NVMAX) + (uint32_t)(j * NVMAX);                            \
+    jm = walk_step<S, G, RC, 4 * G, true, SMALL>(CUR, P1, P2, T, in, dn, WL, hmask,         \
+                                                 last_word);                                \
+    if (jm < G) {                                                                           \
+      rot = 3;                                                                              \
+      break;                                                                                \
     }                                                                                       \
     da = dn;                                                                                \
   }
-  int rot;
+  int rot, jm = G;
   for (;;) {
     HC_WALK_STEP(A, C, B, 0)
     HC_WALK_STEP(B, A, C, 1)
     HC_WALK_STEP(C, B, A, 2)
   }
 #undef HC_WALK_STEP
+  if (rot == 3) { // a window of the block two behind the newest one has a match
+    match = true;
+    return da - (uint32_t)(G * NVMAX) + (uint32_t)(jm * NVMAX);
+  }
   if (rot == 0)
     return walk_drain<S, G, 2, SMALL>(C, B, true, T, in, da, WL, match);
   if (rot == 1)

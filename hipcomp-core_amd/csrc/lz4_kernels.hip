@@ -859,13 +859,13 @@ __device__ __forceinline__ int walk_step(
   constexpr int NVMAX = kWave - 3 / S;
   constexpr int R1 = (RC + 2) % 3; // slot of p1, and of the block two ahead of cur
   constexpr int R2 = (RC + 1) % 3; // slot of p2
-  walk_load<S, G, true, R1>(in, d_cur + (uint32_t)(2 * G * NVMAX), W.sig, last_word);
-  agpr_take4<4 * RC, WORDS_YOUNGER>(cur.word);
   // The LDS operations of the step before (long done) are taken off the
   // counter here, in one instruction: it holds 15, a step issues 12 to 20, and
   // the compiler otherwise keeps it in range with a wait in front of every LDS
   // operation of this step.
   __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+  walk_load<S, G, true, R1>(in, d_cur + (uint32_t)(2 * G * NVMAX), W.sig, last_word);
+  agpr_take4<4 * RC, WORDS_YOUNGER>(cur.word);
   walk_tables<S, G>(cur, T, d_cur, W, hmask);
   walk_probe<S, G, R1, SMALL>(p1, T, in);
   if (!HAVE_P2)

@@ -535,9 +535,14 @@ struct WalkBlock
   uint32_t hpos[G];
   uint32_t tag[G];
   uint32_t pos[G];    // my element
-  uint16_t h_old[G];  // (kept as narrow as the tables hold them: a widening here makes the
-  uint8_t t_old[G];   //  compiler wait for the lookup in the step that issued it)
-  uint16_t rb[G];     // my slot after the window's insert
+  // What the tables held / hold.  Read by inline asm (walk_tables) so that the
+  // compiler takes the registers as the full 32-bit values ds_read_u16 /
+  // ds_read_u8 make of them (through its own loads it masks each of them again,
+  // 8 to 12 instructions a step) -- and therefore waited for by hand:
+  // lgkmcnt(0) at the start of every step, of the roll-back and of the drain.
+  uint32_t h_old[G];  // my slot before the window
+  uint32_t t_old[G];  // ... and its tag
+  uint32_t rb[G];     // my slot after the window's insert
   uint32_t at[G];     // element whose 4 bytes were fetched as my candidate's; pos = none
   uint32_t sharer;    // != 0: I share window lane 31's slot in some window of the block
 };
@@ -625,10 +630,11 @@ __device__ __forceinline__ void walk_tables(
     B.tag[k] = tag_of(hs);
     B.pos[k] = d0 + (uint32_t)(k * NVMAX) + W.sig;
     const uint32_t pa = T.pos_lds + 2u * hp, ta = T.tag_lds + hp;
-    B.h_old[k] = T.pos[hp];
     if (TT::tags)
-      B.t_old[k] = T.tag[hp];
-    lds_lane_exchange_fence();
+      asm volatile("ds_read_u16 %0, %2\n\tds_read_u8 %1, %3"
+                   : "=&v"(B.h_old[k]), "=&v"(B.t_old[k]) : "v"(pa), "v"(ta) : "memory");
+    else
+      asm volatile("ds_read_u16 %0, %1" : "=&v"(B.h_old[k]) : "v"(pa) : "memory");
     // the insert rule (insert_sigma) per lane: a lane in window lane 31's slot
     // stores to the scratch slot instead and notes that it shares (window
     // lane 63 of a 64-lane window stores in any case but is a sharer like any
@@ -664,18 +670,16 @@ __device__ __forceinline__ void walk_tables(
                    : "s"(h31), "v"(mine), "v"(W.scratch_pos), "v"(pa), "v"(B.pos[k])
                    : "vcc", "memory");
     (void)ta_st;
-    B.rb[k] = T.pos[hp];
-    lds_lane_exchange_fence();
+    asm volatile("ds_read_u16 %0, %1" : "=&v"(B.rb[k]) : "v"(pa) : "memory");
   }
 }
 
 // What the lookups of a block returned: the candidates that cannot be ruled
 // out are fetched.  ONE load per window whatever the data (lanes without a
 // candidate re-read their own window word, a line that is in L1), so that the
-// loads in flight can be counted.  The table entries go into the asm as the
-// LDS reads left them (ds_read_u16 / ds_read_u8 fill the register with
-// zeroes); the statements are volatile so that the compiler cannot move them --
-// and with them the wait for the lookups -- up into the step that issued those.
+// loads in flight can be counted.  The table entries are what walk_tables'
+// own ds_read_u16 / ds_read_u8 left in the registers (zero-extended by the
+// hardware, waited for at the start of the step).
 // SMALL: the chunk has at most 65536 BYTES, so a slot's position is the
 // candidate itself and its distance always fits.
 template <int S, int G, int R, bool SMALL, class TT>
@@ -694,13 +698,13 @@ __device__ __forceinline__ void walk_probe(WalkBlock<G>& B, const TT& T, cgptr i
                      "v_cmp_ne_u32_e32 vcc, 0xffff, %2\n\t"
                      "v_cndmask_b32_e32 %0, %1, %0, vcc"
                      : "=&v"(at)
-                     : "v"(B.pos[k]), "v"((uint32_t)B.h_old[k]), "v"((uint32_t)B.t_old[k]), "v"(B.tag[k]), "s"(tag_bits)
+                     : "v"(B.pos[k]), "v"(B.h_old[k]), "v"(B.t_old[k]), "v"(B.tag[k]), "s"(tag_bits)
                      : "vcc");
       else
         asm volatile("v_cmp_ne_u32_e32 vcc, 0xffff, %2\n\t"
                      "v_cndmask_b32_e32 %0, %1, %2, vcc"
                      : "=&v"(at)
-                     : "v"(B.pos[k]), "v"((uint32_t)B.h_old[k])
+                     : "v"(B.pos[k]), "v"(B.h_old[k])
                      : "vcc");
     } else {
       // candidate = nearest element before mine with the slot's low 16 bits,
@@ -716,7 +720,7 @@ __device__ __forceinline__ void walk_probe(WalkBlock<G>& B, const TT& T, cgptr i
                    "v_cmp_ne_u32_e32 vcc, 0xffff, %3\n\t"
                    "v_cndmask_b32_e32 %0, %2, %0, vcc"
                    : "=&v"(at), "=&v"(back)
-                   : "v"(B.pos[k]), "v"((uint32_t)B.h_old[k]), "s"(65535u / S)
+                   : "v"(B.pos[k]), "v"(B.h_old[k]), "s"(65535u / S)
                    : "vcc");
       if (TT::tags) {
         uint32_t tdiff;
@@ -725,7 +729,7 @@ __device__ __forceinline__ void walk_probe(WalkBlock<G>& B, const TT& T, cgptr i
                      "v_cmp_eq_u32_e32 vcc, 0, %1\n\t"
                      "v_cndmask_b32_e32 %0, %2, %0, vcc"
                      : "+v"(at), "=&v"(tdiff)
-                     : "v"(B.pos[k]), "v"((uint32_t)B.t_old[k]), "v"(B.tag[k]), "s"(tag_bits)
+                     : "v"(B.pos[k]), "v"(B.t_old[k]), "v"(B.tag[k]), "s"(tag_bits)
                      : "vcc");
       }
     }
@@ -773,7 +777,7 @@ __device__ __forceinline__ int walk_decide(
                  "v"(cand_word[1]), "v"(B.word[1]), "v"(B.at[1]), "v"(B.pos[1]),
                  "v"(cand_word[2]), "v"(B.word[2]), "v"(B.at[2]), "v"(B.pos[2]),
                  "v"(cand_word[3]), "v"(B.word[3]), "v"(B.at[3]), "v"(B.pos[3]),
-                 "v"((uint32_t)B.rb[0]), "v"((uint32_t)B.rb[1]), "v"((uint32_t)B.rb[2]), "v"((uint32_t)B.rb[3])
+                 "v"(B.rb[0]), "v"(B.rb[1]), "v"(B.rb[2]), "v"(B.rb[3])
                : "vcc");
   // the one trip to the scalar unit of the block
   const uint64_t hits = wave_ballot(miss == 0);
@@ -874,6 +878,7 @@ __device__ __forceinline__ int walk_step(
   agpr_take4<12 + 4 * R2, 2 * G>(cand_word);
   const int j = walk_decide<S, G>(p2, cand_word, W);
   if (__builtin_expect(j < G, 0)) {
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): what cur's lookups of this step read
     walk_undo<G>(cur, T, 0, W.validc);
     walk_undo<G>(p1, T, 0, W.validc);
     walk_undo<G>(p2, T, j, W.validc);
@@ -892,6 +897,7 @@ __device__ __forceinline__ uint32_t walk_drain(
 {
   constexpr int NVMAX = kWave - 3 / S;
   constexpr int RY = (RX + 2) % 3;
+  __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): x's lookups
   walk_probe<S, G, RX, SMALL>(x, T, in);
   uint32_t cw[G];
   if (have_y) {

@@ -847,12 +847,14 @@ __device__ __forceinline__ void walk_undo(const WalkBlock<G>& B, const TT& T, in
 //                          tables (walk_tables);
 //   p2  (two blocks back)  its candidate words, asked for a whole step ago,
 //                          decide whether the walk goes on (walk_decide).
-// Order in a step: word loads for the block two ahead, tables of cur, probe
-// of p1, decision about p2 -- so nothing is used before a whole step has
-// passed since it was asked for.  Vector memory operations complete in issue
-// order; a step issues G word loads, then G candidate loads, so behind the
-// words of `cur` WORDS_YOUNGER = 4 G loads have been issued (2 G and 3 G in
-// the first two steps of a walk) and behind the candidate words of p2 2 G.
+// Order in a step: candidates of p1 asked for, word loads for the block two
+// ahead, tables of cur, decision about p2 -- so nothing is used before a whole
+// step has passed since it was asked for, and (vector memory operations
+// complete in issue order) the candidate words of p2 wait for no load younger
+// than the words asked for TWO steps ago: a step issues G candidate loads,
+// then G word loads, so behind the words of `cur` WORDS_YOUNGER = 4 G loads
+// have been issued (3 G in the first step of a walk) and behind the candidate
+// words of p2 3 G.
 // Returns the window of p2 that has a match (the tables are then back in the
 // state before that window), G if none (or no p2 yet).
 template <int S, int G, int RC, int WORDS_YOUNGER, bool HAVE_P2, bool SMALL, class TT>
@@ -868,14 +870,14 @@ __device__ __forceinline__ int walk_step(
   // the compiler otherwise keeps it in range with a wait in front of every LDS
   // operation of this step.
   __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+  walk_probe<S, G, R1, SMALL>(p1, T, in);
   walk_load<S, G, true, R1>(in, d_cur + (uint32_t)(2 * G * NVMAX), W.sig, last_word);
   agpr_take4<4 * RC, WORDS_YOUNGER>(cur.word);
   walk_tables<S, G>(cur, T, d_cur, W, hmask);
-  walk_probe<S, G, R1, SMALL>(p1, T, in);
   if (!HAVE_P2)
     return G;
   uint32_t cand_word[G];
-  agpr_take4<12 + 4 * R2, 2 * G>(cand_word);
+  agpr_take4<12 + 4 * R2, 3 * G>(cand_word);
   const int j = walk_decide<S, G>(p2, cand_word, W);
   if (__builtin_expect(j < G, 0)) {
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): what cur's lookups of this step read
@@ -953,8 +955,8 @@ __device__ __forceinline__ uint32_t walk_run(
     da = dn;                                                                                \
   }
   // (the first two steps have fewer loads behind them and nothing to decide yet)
-  HC_WALK_STEP(B, A, C, 1, 2 * G, false, false)
-  HC_WALK_STEP(C, B, A, 2, 3 * G, true, true)
+  HC_WALK_STEP(B, A, C, 1, 3 * G, false, false)
+  HC_WALK_STEP(C, B, A, 2, 4 * G, true, true)
 #undef HC_WALK_STEP
   // The steady state.  It is left for the drain through ONE exit behind the
   // loop (`rot` = the step that did not run): with the drain inside the loop

@@ -1414,8 +1414,14 @@ __device__ __forceinline__ void compress_wave_far(
         // that is anything else is redone by the general code below, and if
         // it had no such table match at all (data of another kind: runs) this
         // path rests until the general code meets one.
+        // The window's words as this path sees them: from memory (`next`) on
+        // entry, from then on the words of the window before, moved down by the
+        // lanes the sequence took (ds_bpermute: the lanes this path looks at are
+        // all there) -- the load of the new window's words is then off the chain
+        // from one sequence to the next; the general code waits for it.
+        uint32_t wnd = next;
         while (straight && token_start == d && d + kFarFastMargin <= L) {
-          const uint32_t word = next;
+          const uint32_t word = wnd;
           const uint32_t hpos = hash_sum(word) & hmask;
           uint32_t h_old = kNullOffset;
           if (lane < kFarFirst)
@@ -1469,6 +1475,8 @@ __device__ __forceinline__ void compress_wave_far(
               out[c + i] = (uint8_t)bt;
             c += lit_bytes + 3;
           }
+          // (`next`: this window's words from memory, long there)
+          wnd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + (uint32_t)k + ml) & 63u) * 4u), (int)next);
           d = mpos + ml;
           token_start = d;
           cold = 0;

@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(kLz4MaxWavesPerGroup * kWave) void lz4_compress_ker
 constexpr int kFarWavesPerGroup = 4;
 constexpr int kFarFirst = 8; // lanes whose table slots are looked up before the rest
 // Elements a window must have ahead of it for the straight-line path: the
-// window, the lanes of the match, 256 bytes of match length, the chunk's tail.
+// window, the lanes of the match, the bytes looked at for the match length, the chunk's tail.
 constexpr uint32_t kFarFastMargin = 400;
 constexpr int kFarGroupsPerCu = 8; // 32 waves: 64 vector registers each
 constexpr uint32_t kFarScratchSlots = 2048; // u16 each, per wave: 128 KiB per CU
@@ -1444,9 +1444,12 @@ __device__ __forceinline__ void compress_wave_far(
           if (duplicate)
             break;
           const uint32_t mloc = read_lane(cand, k), mpos = d + (uint32_t)k;
-          // match length: the first 256 bytes (the margin keeps them inside the limit)
-          const uint32_t x = load_u32_any(in + (size_t)mloc * S + 4u * (uint32_t)lane)
-                             ^ load_u32_any(in + (size_t)mpos * S + 4u * (uint32_t)lane);
+          // match length: the first 32 bytes (8 lanes, one line each side) -- a
+          // match that long is not for this path anyway
+          uint32_t x = 0;
+          if (lane < 8)
+            x = load_u32_any(in + (size_t)mloc * S + 4u * (uint32_t)lane)
+                ^ load_u32_any(in + (size_t)mpos * S + 4u * (uint32_t)lane);
           const uint32_t diff_at = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
           const uint64_t stop = wave_ballot(diff_at < 4u);
           if (stop == 0)

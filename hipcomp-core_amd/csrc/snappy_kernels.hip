@@ -46,6 +46,9 @@ __device__ __forceinline__ uint32_t snap_hash(uint32_t v)
   return (v * ((1u << 20) + 0x2a00u + 0x6au + 1u)) >> (32 - kHashBits);
 }
 
+// lanes of a window whose table candidates the encoder fetches before the others'
+constexpr int kFirstLanes = 8;
+
 __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     const uint8_t* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
@@ -119,7 +122,12 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
       if (toff >= p)
         toff = (toff >= 0x10000u) ? toff - 0x10000u : p;
       const bool tprobe = valid4 && toff < p && toff + kMaxCopyDistance >= my;
-      const uint32_t tword = load_u32_any(src + (tprobe ? toff : min(my, last_word)));
+      // Candidates are fetched for the first kFirstLanes lanes only: that is
+      // where the match of a window of data that compresses is, and a 64-lane
+      // gather is 64 memory transactions.  The other lanes re-read their own
+      // word (one line); their candidates follow below if no early lane hits.
+      const bool tprobe1 = tprobe && lane < kFirstLanes;
+      const uint32_t tword = load_u32_any(src + (tprobe1 ? toff : min(my, last_word)));
 
       // HashMatchAny (reference :157-172): all 64 lanes take part, lanes past
       // the end with hash 0.  Post lane ids (highest lane survives), read the
@@ -150,10 +158,19 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
       const uint32_t lmd = (uint32_t)__builtin_amdgcn_ds_bpermute(
           (int)(min(lml, (uint32_t)lane) * 4u), (int)data32);
       const bool local_hit = valid4 && lml < (uint32_t)lane && lmd == data32;
-      const bool table_hit = !local_hit && tprobe && tword == data32;
+      bool table_hit = !local_hit && tprobe1 && tword == data32;
       const uint32_t offset = local_hit ? p + lml : toff;
 
-      const uint64_t match_mask = wave_ballot(local_hit || table_hit);
+      uint64_t match_mask = wave_ballot(local_hit || table_hit);
+      if ((match_mask & ((1ull << kFirstLanes) - 1ull)) == 0) {
+        // no hit among the first lanes: the first hit of all lanes decides
+        const bool tprobe2 = tprobe && lane >= kFirstLanes;
+        if (wave_ballot(tprobe2) != 0) {
+          const uint32_t tword2 = load_u32_any(src + (tprobe2 ? toff : min(my, last_word)));
+          table_hit = !local_hit && tprobe2 && tword2 == data32;
+          match_mask |= wave_ballot(table_hit);
+        }
+      }
       if (match_mask) {
         literal_cnt = (uint32_t)__builtin_ctzll(match_mask);
         distance = read_lane(my - offset, (int)literal_cnt);

@@ -385,6 +385,16 @@ def main():
         # no launcher: become one.  Nothing has touched the GPU in this process.
         sys.exit(self_spawn(sys.argv[1:], args.gpus))
 
+    # Exactly ONE line goes to stdout, the JSON line: everything else this process
+    # or a library it loads writes there (gloo announces its ranks on stdout) is sent
+    # to stderr from here on.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     import numpy as np
     import torch
 
@@ -403,8 +413,8 @@ def main():
         v, w = aggregate_throughput(1.0 + rank, (hi - lo) * CHUNK, args.steps, dist if world > 1 else None, "cpu")
         v5, _ = aggregate_throughput(1.0, (hi5 - lo5) * CHUNK, args.steps, dist if world > 1 else None, "cpu")
         if rank == 0:
-            print(json.dumps({"dry_run": True, "value": None, "n_gpus": world, "weak_bytes_per_step_GB": v * w / args.steps,
-                              "strong_bytes_per_step_GB": v5 * 1.0 / args.steps, "slowest_rank_wall_s": w}), flush=True)
+            emit({"dry_run": True, "value": None, "n_gpus": world, "weak_bytes_per_step_GB": v * w / args.steps,
+                  "strong_bytes_per_step_GB": v5 * 1.0 / args.steps, "slowest_rank_wall_s": w})
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -552,7 +562,7 @@ def main():
         del cols
         res["extra_keys"] = rows
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit(res)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

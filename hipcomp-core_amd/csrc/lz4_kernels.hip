@@ -1050,16 +1050,19 @@ __device__ __forceinline__ void emit_match(
 // small-chunk GPU tests (many tickets per wave) are its regression test.
 __device__ __forceinline__ uint32_t take_ticket(uint32_t* ticket, uint32_t count)
 {
-  uint32_t t;
+  // (offset and addend are made inside the statement from scalars: as vector
+  // operands they would each hold a register for the whole kernel)
+  uint32_t t, addend, zero;
   uint64_t saved;
-  const uint32_t zero = 0;
-  asm volatile("s_mov_b64 %1, exec\n\t"
-               "s_and_b64 exec, %1, 1\n\t"
-               "global_atomic_add %0, %2, %3, %4 sc0\n\t"
+  asm volatile("s_mov_b64 %3, exec\n\t"
+               "s_and_b64 exec, %3, 1\n\t"
+               "v_mov_b32_e32 %1, 0\n\t"
+               "v_mov_b32_e32 %2, %4\n\t"
+               "global_atomic_add %0, %1, %2, %5 sc0\n\t"
                "s_waitcnt vmcnt(0)\n\t"
-               "s_mov_b64 exec, %1"
-               : "=&v"(t), "=&s"(saved)
-               : "v"(zero), "v"(count), "s"(ticket)
+               "s_mov_b64 exec, %3"
+               : "=&v"(t), "=&v"(zero), "=&v"(addend), "=&s"(saved)
+               : "s"(count), "s"(ticket)
                : "memory", "scc");
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 }
@@ -1354,6 +1357,149 @@ __device__ __forceinline__ void far_insert_first(
   }
 }
 
+// ---------------------------------------------------------------------------
+// The common window of data that compresses, as straight a line as it can be
+// written (the far kernel is bound by its instruction count, the scalar one
+// above all -- 8 waves share a SIMD's issue slots -- and by trips to memory):
+// no literals pending, the match among the first kFarFirst lanes, a short
+// sequence.  Two forms:
+//   lean (WIDE = false)  a table match, no duplicate below it, match < 19 bytes;
+//   wide                 a table match or a lane with an equal lower lane, at
+//                        most one match length byte (match < 274 bytes).
+// Nothing is changed before all of that is known; a window that is anything
+// else is left to the caller.  Returns false if the window it stopped at had
+// no match of its kind among the first lanes at all (the caller lets the form
+// rest until its general code meets one).  only_one: take one window at most.
+//
+// The window's words as this path sees them: from memory (`next`) on entry,
+// from then on the words of the window before, moved down by the lanes the
+// sequence took (ds_bpermute: the lanes this path looks at are all there) --
+// the load of the new window's words is then off the chain from one sequence
+// to the next; the general code waits for it.
+// ---------------------------------------------------------------------------
+template <int S, bool WIDE>
+__device__ __forceinline__ bool far_straight(
+    cgptr __restrict__ in, gptr __restrict__ out, HC_GLOBAL uint16_t* const table, uint16_t* const scr,
+    const uint32_t hmask, const uint32_t L, const uint32_t last_word, const int lane, uint32_t& d, uint32_t& c,
+    uint32_t& token_start, int& cold, uint32_t& next, const int only_one)
+{
+  uint32_t wnd = next;
+  bool armed = true;
+  while (d + kFarFastMargin <= L) {
+    const uint32_t word = wnd;
+    const uint32_t hpos = hash_sum(word) & hmask;
+    uint32_t h_old = kNullOffset;
+    if (lane < kFarFirst)
+      h_old = table[hpos];
+    const uint32_t pos = d + (uint32_t)lane;
+    const uint32_t back = (pos - 1u - h_old) & 0xFFFFu; // (see window_candidate)
+    const uint32_t cand = pos - 1u - back;
+    const bool usable = (h_old != kNullOffset) & (back < 65535u / S);
+    const uint32_t cand_word = load_u32_any(in + (size_t)(usable ? cand : pos) * S);
+    const uint64_t tmask = wave_ballot(usable & (cand_word == word));
+    int f;
+    uint32_t mloc;
+    if (!WIDE) {
+      if (tmask == 0) {
+        armed = false;
+        break;
+      }
+      f = __builtin_ctzll(tmask); // < kFarFirst
+      // a duplicate among lanes 0..f-1 would come first
+      bool duplicate = false;
+      for (int u = 0; u + 1 < f; ++u)
+        duplicate |= (wave_ballot(word == read_lane(word, u)) & lanes_below<64>(f) & ~lanes_below<64>(u + 1)) != 0;
+      if (duplicate)
+        break;
+      mloc = read_lane(cand, f);
+    } else {
+      const int k = tmask ? __builtin_ctzll(tmask) : kFarFirst; // first lane with a table match
+      // a lane below k with an equal lower lane comes first (reference :868-894).
+      // Among the first 8 lanes (one DPP row): my word against the 7 lanes below.
+      uint64_t dups = 0;
+      if (k >= 2) {
+        // row_shr:j -- lane t reads lane t - j; lanes without one keep ~word
+#define HC_EQ_BELOW(j) \
+  ((uint32_t)__builtin_amdgcn_update_dpp((int)~word, (int)word, 0x110 + (j), 0xF, 0xF, false) == word ? 1u : 0u)
+        const uint32_t eq = HC_EQ_BELOW(1) | HC_EQ_BELOW(2) | HC_EQ_BELOW(3) | HC_EQ_BELOW(4) | HC_EQ_BELOW(5)
+                            | HC_EQ_BELOW(6) | HC_EQ_BELOW(7);
+#undef HC_EQ_BELOW
+        dups = wave_ballot(eq != 0) & lanes_below<64>(k);
+      }
+      if (dups) {
+        f = __builtin_ctzll(dups);
+        mloc = d + (uint32_t)__builtin_ctzll(wave_ballot(word == read_lane(word, f))); // lowest lane holding the word
+      } else if (tmask) {
+        f = k;
+        mloc = read_lane(cand, k);
+      } else {
+        armed = false;
+        break;
+      }
+    }
+    const uint32_t mpos = d + (uint32_t)f;
+    // match length: the first 32 bytes (8 lanes, one line each side); the wide
+    // form goes on with the general search
+    uint32_t x = 0;
+    if (lane < 8)
+      x = load_u32_any(in + (size_t)mloc * S + 4u * (uint32_t)lane)
+          ^ load_u32_any(in + (size_t)mpos * S + 4u * (uint32_t)lane);
+    const uint32_t diff_at = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+    const uint64_t stop = wave_ballot(diff_at < 4u);
+    uint32_t ml;
+    if (stop) {
+      const int sl = __builtin_ctzll(stop);
+      ml = (4u * (uint32_t)sl + read_lane(diff_at, sl)) / S;
+    } else if (WIDE) {
+      ml = match_length<S>(in, mloc, mpos, L - mpos - (5 + S - 1) / S, lane);
+    } else {
+      break;
+    }
+    const uint32_t lit_bytes = (uint32_t)f * S, match_bytes = ml * S;
+    if (lit_bytes >= 15u || match_bytes >= (WIDE ? 19u + 255u : 19u))
+      break; // (more length bytes than this path writes)
+    // ---- decided: insert the first f lanes, write the sequence in ONE store
+    // (token, literals from the window registers, offset, wide: at most one
+    // match length byte), move on
+    if (f > 0)
+      far_store_masked(table, hpos, pos & 0xFFFFu, slot_tops(hpos, lanes_below<64>(f), scr, lane), lane);
+    {
+      const uint32_t offset_bytes = (((mpos - mloc) & 0xFFFFu) * S) & 0xFFFFu;
+      const uint32_t ext = (WIDE && match_bytes >= 19u) ? 1u : 0u;
+      const uint32_t i = (uint32_t)lane, li = i - 1u;
+      const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((li / S) * 4u), (int)word);
+      uint32_t bt = (src >> (8u * (li % S))) & 0xFFu;
+      if (i == 0)
+        bt = (lit_bytes << 4) | (ext ? 15u : match_bytes - 4u);
+      else if (i == lit_bytes + 1)
+        bt = offset_bytes & 0xFFu;
+      else if (i == lit_bytes + 2)
+        bt = offset_bytes >> 8;
+      else if (WIDE && i == lit_bytes + 3)
+        bt = match_bytes - 19u;
+      if (i < lit_bytes + 3 + ext)
+        out[c + i] = (uint8_t)bt;
+      c += lit_bytes + 3 + ext;
+    }
+    // the next window's first lanes from this window's words (`next`: from
+    // memory, long there) if the sequence left them inside it
+    const uint32_t moved = (uint32_t)f + ml;
+    wnd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + moved) & 63u) * 4u), (int)next);
+    d = mpos + ml;
+    token_start = d;
+    cold = 0;
+    next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+    if (only_one)
+      break;
+    if (WIDE && __builtin_expect(moved > 56u, 0)) {
+      // (a real branch: as a select it would make every trip wait for the load)
+      asm volatile("" ::: "memory");
+      wnd = next;
+    }
+  }
+  return armed;
+}
+
 template <int S>
 __device__ __forceinline__ void compress_wave_far(
     const uint8_t* const* __restrict__ in_ptrs,
@@ -1402,89 +1548,17 @@ __device__ __forceinline__ void compress_wave_far(
         next = load_u32_any(in + (size_t)min((uint32_t)lane, last_word) * S);
       int cold = 0;
       uint32_t token_start = 0;
-      // the straight-line path below is tried while it keeps finding its kind of window
-      bool straight = true;
+      // the straight-line paths (far_straight) are tried while they keep finding their kind of window
+      bool lean = true, wide = true;
       while (d < L) {
-        // ---- the common window of data that compresses, as straight a line
-        // as it can be written (this kernel is bound by its instruction
-        // count, the scalar one above all: 8 waves share a SIMD's issue
-        // slots): no literals pending, a table match of one of the first
-        // kFarFirst lanes, no duplicate among the lanes below it, a short
-        // match.  Nothing is changed before all of that is known; a window
-        // that is anything else is redone by the general code below, and if
-        // it had no such table match at all (data of another kind: runs) this
-        // path rests until the general code meets one.
-        // The window's words as this path sees them: from memory (`next`) on
-        // entry, from then on the words of the window before, moved down by the
-        // lanes the sequence took (ds_bpermute: the lanes this path looks at are
-        // all there) -- the load of the new window's words is then off the chain
-        // from one sequence to the next; the general code waits for it.
-        uint32_t wnd = next;
-        while (straight && token_start == d && d + kFarFastMargin <= L) {
-          const uint32_t word = wnd;
-          const uint32_t hpos = hash_sum(word) & hmask;
-          uint32_t h_old = kNullOffset;
-          if (lane < kFarFirst)
-            h_old = table[hpos];
-          const uint32_t pos = d + (uint32_t)lane;
-          const uint32_t back = (pos - 1u - h_old) & 0xFFFFu; // (see window_candidate)
-          const uint32_t cand = pos - 1u - back;
-          const bool usable = (h_old != kNullOffset) & (back < 65535u / S);
-          const uint32_t cand_word = load_u32_any(in + (size_t)(usable ? cand : pos) * S);
-          const uint64_t tmask = wave_ballot(usable & (cand_word == word));
-          if (tmask == 0) {
-            straight = false;
-            break;
-          }
-          const int k = __builtin_ctzll(tmask); // < kFarFirst
-          // a duplicate among lanes 0..k-1 would come first
-          bool duplicate = false;
-          for (int u = 0; u + 1 < k; ++u)
-            duplicate |= (wave_ballot(word == read_lane(word, u)) & lanes_below<64>(k) & ~lanes_below<64>(u + 1)) != 0;
-          if (duplicate)
-            break;
-          const uint32_t mloc = read_lane(cand, k), mpos = d + (uint32_t)k;
-          // match length: the first 32 bytes (8 lanes, one line each side) -- a
-          // match that long is not for this path anyway
-          uint32_t x = 0;
-          if (lane < 8)
-            x = load_u32_any(in + (size_t)mloc * S + 4u * (uint32_t)lane)
-                ^ load_u32_any(in + (size_t)mpos * S + 4u * (uint32_t)lane);
-          const uint32_t diff_at = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
-          const uint64_t stop = wave_ballot(diff_at < 4u);
-          if (stop == 0)
-            break;
-          const int sl = __builtin_ctzll(stop);
-          const uint32_t ml = (4u * (uint32_t)sl + read_lane(diff_at, sl)) / S;
-          const uint32_t lit_bytes = (uint32_t)k * S, match_bytes = ml * S;
-          if (lit_bytes >= 15u || match_bytes >= 19u)
-            break;
-          // ---- decided: insert the first k lanes, write the sequence (as
-          // emit_match's short form), move on
-          if (k > 0)
-            far_store_masked(table, hpos, pos & 0xFFFFu, slot_tops(hpos, lanes_below<64>(k), scr, lane), lane);
-          {
-            const uint32_t offset_bytes = (((mpos - mloc) & 0xFFFFu) * S) & 0xFFFFu;
-            const uint32_t i = (uint32_t)lane, li = i - 1u;
-            const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((li / S) * 4u), (int)word);
-            uint32_t bt = (src >> (8u * (li % S))) & 0xFFu;
-            if (i == 0)
-              bt = (lit_bytes << 4) | ((match_bytes - 4u) & 0x0Fu);
-            else if (i == lit_bytes + 1)
-              bt = offset_bytes & 0xFFu;
-            else if (i == lit_bytes + 2)
-              bt = offset_bytes >> 8;
-            if (i < lit_bytes + 3)
-              out[c + i] = (uint8_t)bt;
-            c += lit_bytes + 3;
-          }
-          // (`next`: this window's words from memory, long there)
-          wnd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + (uint32_t)k + ml) & 63u) * 4u), (int)next);
-          d = mpos + ml;
-          token_start = d;
-          cold = 0;
-          next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
-        }
+        // ---- the common windows of data that compresses (far_straight): the
+        // lean form while table matches keep coming, else the wide one; when the
+        // lean form is armed the wide one only takes the window it stumbled at
+        if (lean && token_start == d)
+          lean = far_straight<S, false>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next, 0);
+        if (wide && token_start == d)
+          wide = far_straight<S, true>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next,
+                                       lean ? 1 : 0);
         if (d + LVM >= L) {
           c = write_sequence(out, c, in + (size_t)token_start * S, len - token_start * S, 0, 0, lane);
           break;
@@ -1528,7 +1602,8 @@ __device__ __forceinline__ void compress_wave_far(
           }
         }
         const Decision D = window_settle(P, f, mlane, tmask);
-        straight |= tmask != 0 && D.f < kFarFirst;
+        lean |= tmask != 0 && D.f < kFarFirst;
+        wide |= D.match && D.f < kFarFirst;
         if (D.match) {
           far_insert_first<NVMAX>(P, table, scr, D.f, perm_addr4, sig, hmask, lane);
           emit_match<S>(out, c, in, token_start, P.d, P.word, D, L, lane, d);

@@ -1830,8 +1830,13 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
         if (wave_ballot((int32_t)bad2 < 0) == 0) {
           if (WRITE_OUT) {
             uint32_t j = i - litf; // match byte index (lanes >= lit)
-            if (wave_ballot(voff < vml2) != 0)
-              j = small_mod(j & 63u, voff); // (lanes below lit: unused)
+            if (wave_ballot(voff < vml2) != 0) { // (lanes below lit: unused)
+              // runs of 1-, 2-, 4-, 8-byte elements: the period is a power of two
+              if (wave_ballot((voff & (voff - 1u)) != 0) == 0)
+                j &= voff - 1u;
+              else
+                j = small_mod(j & 63u, voff);
+            }
             const int32_t a = i < litf ? (int32_t)i : (int32_t)(litf + j - voff);
             const uint32_t sidx = idx + 1u + (uint32_t)max(a, 0);
             const uint32_t sword = (uint32_t)__builtin_amdgcn_ds_bpermute(

@@ -1918,6 +1918,10 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
             // long match, source and destination do not overlap (offset >= ml)
             wave_copy(dst, src, ml, lane);
           }
+        } else if ((offset & (offset - 1u)) == 0) {
+          // the period is a power of two (runs of 1-, 2-, 4-, 8-byte elements)
+          for (uint32_t i = (uint32_t)lane; i < ml; i += kWave)
+            dst[i] = src[i & (offset - 1u)];
         } else {
           for (uint32_t i = (uint32_t)lane; i < ml; i += kWave)
             dst[i] = src[i % offset];

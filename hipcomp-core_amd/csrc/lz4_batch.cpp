@@ -8,8 +8,8 @@
 //     LZ4Batch.cpp:76,160,177 call CHECK_NOT_NULL outside the try block);
 //   * batch_size == 0 is a successful no-op (the reference launches a
 //     zero-sized grid and reports the resulting HIP error);
-//   * of device_temp_ptr the first 12 bytes hold the chunk ticket counter of
-//     the persistent compress kernels and two sampling counters; the rest
+//   * of device_temp_ptr the first 16 bytes hold the chunk ticket counter of
+//     the persistent compress kernels and three sampling counters; the rest
 //     holds hash tables only for data that compresses well (one per resident
 //     wave, not one per chunk: lz4_kernels.hip "far"), otherwise the tables
 //     live in LDS.  temp_bytes is checked against the contract size, so
@@ -114,8 +114,8 @@ hipcompStatus_t hipcompBatchedLZ4CompressAsync(
   if (batch_size > 0x7FFFFFFFull) // the ticket counter runs past batch_size by up to waves x 64
     return fail(fn, "batch_size must be below 2^31");
   HCAMD_DEVICE_POINTER(fn, device_temp_ptr);
-  // the chunk ticket counter and the two counters of the sampling kernel: the
-  // first three 4-byte aligned words of the temp buffer -- if the (contract-
+  // the chunk ticket counter and the three counters of the sampling kernel: the
+  // first four 4-byte aligned words of the temp buffer -- if the (contract-
   // sized) buffer is too small to hold them, the kernel runs without
   uint32_t* ticket = nullptr;
   // behind them, 16-byte aligned: hash tables of the "far" shape, as many as fit
@@ -124,9 +124,9 @@ hipcompStatus_t hipcompBatchedLZ4CompressAsync(
   {
     const uintptr_t base = reinterpret_cast<uintptr_t>(device_temp_ptr);
     const uintptr_t aligned = (base + 3u) & ~uintptr_t(3);
-    if (aligned + 3 * sizeof(uint32_t) <= base + temp_bytes) {
+    if (aligned + 4 * sizeof(uint32_t) <= base + temp_bytes) {
       ticket = reinterpret_cast<uint32_t*>(aligned);
-      const uintptr_t tables = (aligned + 3 * sizeof(uint32_t) + 15u) & ~uintptr_t(15);
+      const uintptr_t tables = (aligned + 4 * sizeof(uint32_t) + 15u) & ~uintptr_t(15);
       if (tables < base + temp_bytes) {
         far_tables = reinterpret_cast<uint16_t*>(tables);
         far_capacity = (base + temp_bytes - tables) / ((ht < 8 ? 8 : ht) * sizeof(uint16_t));

@@ -1227,15 +1227,18 @@ __device__ __forceinline__ void compress_wave(
 //   "far"   tables in device memory, 32 waves per CU, no tags, no walk (64
 //           vector registers): for data that has a match in nearly every
 //           window (compress_wave_far below).
-// `mode` (may be null) points at the two counters of the sampling kernel: a
+// `mode` (may be null) points at the three counters of the sampling kernel: a
 // kernel whose shape is not the one they call for leaves at once.
-constexpr uint32_t kModeMix = 1, kModeFar = 2;
+constexpr uint32_t kModeMix = 1, kModeFar = 2, kModeFarWide = 3;
 
-// {words that repeated, words looked at} -> shape
+// {words that repeated, words looked at, words equal to one 1, 2, 4 or 8 bytes before} -> shape
 __device__ __forceinline__ uint32_t sampled_mode(const uint32_t* counters)
 {
-  const uint32_t repeats = uniform(counters[0]), looked = uniform(counters[1]);
-  return (looked != 0 && repeats * 4u > looked) ? kModeFar : kModeMix;
+  const uint32_t repeats = uniform(counters[0]), looked = uniform(counters[1]), near = uniform(counters[2]);
+  if (looked == 0 || repeats * 4u <= looked)
+    return kModeMix;
+  // data that compresses: mostly by words repeating a few bytes on (runs) or not
+  return near * 2u > looked ? kModeFarWide : kModeFar;
 }
 
 template <int S>
@@ -1500,7 +1503,7 @@ __device__ __forceinline__ bool far_straight(
   return armed;
 }
 
-template <int S>
+template <int S, bool WIDE>
 __device__ __forceinline__ void compress_wave_far(
     const uint8_t* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
@@ -1548,17 +1551,13 @@ __device__ __forceinline__ void compress_wave_far(
         next = load_u32_any(in + (size_t)min((uint32_t)lane, last_word) * S);
       int cold = 0;
       uint32_t token_start = 0;
-      // the straight-line paths (far_straight) are tried while they keep finding their kind of window
-      bool lean = true, wide = true;
+      // the straight-line path (far_straight) is tried while it keeps finding its kind of window
+      bool straight = true;
       while (d < L) {
-        // ---- the common windows of data that compresses (far_straight): the
-        // lean form while table matches keep coming, else the wide one; when the
-        // lean form is armed the wide one only takes the window it stumbled at
-        if (lean && token_start == d)
-          lean = far_straight<S, false>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next, 0);
-        if (wide && token_start == d)
-          wide = far_straight<S, true>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next,
-                                       lean ? 1 : 0);
+        // ---- the common windows of data that compresses (far_straight, the
+        // form of this kernel)
+        if (straight && token_start == d)
+          straight = far_straight<S, WIDE>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next, 0);
         if (d + LVM >= L) {
           c = write_sequence(out, c, in + (size_t)token_start * S, len - token_start * S, 0, 0, lane);
           break;
@@ -1602,8 +1601,7 @@ __device__ __forceinline__ void compress_wave_far(
           }
         }
         const Decision D = window_settle(P, f, mlane, tmask);
-        lean |= tmask != 0 && D.f < kFarFirst;
-        wide |= D.match && D.f < kFarFirst;
+        straight |= (WIDE ? D.match : tmask != 0) && D.f < kFarFirst;
         if (D.match) {
           far_insert_first<NVMAX>(P, table, scr, D.f, perm_addr4, sig, hmask, lane);
           emit_match<S>(out, c, in, token_start, P.d, P.word, D, L, lane, d);
@@ -1625,7 +1623,9 @@ __device__ __forceinline__ void compress_wave_far(
 }
 
 // tables = far_waves x max(ht_size, 8) x u16 in device memory, 16-byte aligned
-template <int S>
+// WIDE: the wide form of the straight-line path (far_straight) instead of the
+// lean one -- one kernel with both forms has either run slower (64 registers)
+template <int S, bool WIDE>
 __global__ __launch_bounds__(kFarWavesPerGroup * kWave, kFarGroupsPerCu) void lz4_compress_kernel_far(
     const uint8_t* const* __restrict__ in_ptrs, const size_t* __restrict__ in_bytes,
     uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ out_bytes,
@@ -1634,11 +1634,11 @@ __global__ __launch_bounds__(kFarWavesPerGroup * kWave, kFarGroupsPerCu) void lz
     const uint32_t* __restrict__ mode)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // kFarScratchSlots x u16 per wave
-  if (mode && sampled_mode(mode) != kModeFar)
+  if (mode && sampled_mode(mode) != (WIDE ? kModeFarWide : kModeFar))
     return;
   const uint32_t wave = uniform((uint32_t)(threadIdx.x >> 6));
   const size_t gw = (size_t)blockIdx.x * kFarWavesPerGroup + wave;
-  compress_wave_far<S>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size,
+  compress_wave_far<S, WIDE>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size,
                        (HC_GLOBAL uint16_t*)(tables + gw * max(ht_size, 8u)), // (16 bytes at least: filled 16 at a time)
                        reinterpret_cast<uint16_t*>(smem) + wave * kFarScratchSlots, batch, ticket,
                        chunks_per_ticket);
@@ -1669,17 +1669,25 @@ __global__ __launch_bounds__(kWave) void lz4_sample_kernel(
   for (int i = lane; i < 16384 / 32; i += kWave)
     seen[i] = 0;
   __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): one wave, LDS operations in order
-  uint32_t repeats = 0;
+  uint32_t repeats = 0, near = 0;
   for (uint32_t p = (uint32_t)lane; p < n; p += kWave) {
-    const uint32_t h = hash_sum(load_u32_any(in + from + p)) & 16383u;
+    const uint32_t w = load_u32_any(in + from + p);
+    const uint32_t h = hash_sum(w) & 16383u;
     const uint32_t old = atomicOr(&seen[h >> 5], 1u << (h & 31u));
     repeats += (old >> (h & 31u)) & 1u;
+    // the word 1, 2, 4 or 8 bytes before (runs of elements of those sizes): from >= 8 here
+    if (from >= 8u)
+      near += (w == load_u32_any(in + from + p - 1u)) | (w == load_u32_any(in + from + p - 2u))
+              | (w == load_u32_any(in + from + p - 4u)) | (w == load_u32_any(in + from + p - 8u));
   }
-  for (int o = 32; o > 0; o >>= 1)
+  for (int o = 32; o > 0; o >>= 1) {
     repeats += __shfl_xor(repeats, o);
+    near += __shfl_xor(near, o);
+  }
   if (lane == 0) {
     atomicAdd(&counters[0], repeats);
     atomicAdd(&counters[1], n);
+    atomicAdd(&counters[2], near);
   }
 }
 
@@ -1991,10 +1999,13 @@ MixKernel mix_kernel_for(int elem_size)
   return elem_size == 1 ? lz4_compress_kernel_mix<1> : elem_size == 2 ? lz4_compress_kernel_mix<2>
                                                                       : lz4_compress_kernel_mix<4>;
 }
-FarKernel far_kernel_for(int elem_size)
+FarKernel far_kernel_for(int elem_size, bool wide)
 {
-  return elem_size == 1 ? lz4_compress_kernel_far<1> : elem_size == 2 ? lz4_compress_kernel_far<2>
-                                                                      : lz4_compress_kernel_far<4>;
+  if (wide)
+    return elem_size == 1 ? lz4_compress_kernel_far<1, true> : elem_size == 2 ? lz4_compress_kernel_far<2, true>
+                                                                               : lz4_compress_kernel_far<4, true>;
+  return elem_size == 1 ? lz4_compress_kernel_far<1, false> : elem_size == 2 ? lz4_compress_kernel_far<2, false>
+                                                                              : lz4_compress_kernel_far<4, false>;
 }
 
 // more than 64 KiB of dynamic LDS has to be asked for, once per kernel and device
@@ -2084,6 +2095,8 @@ Lz4Mode lz4_mode_from_environment()
       return Lz4Mode::Mix;
     if (e && std::strcmp(e, "far") == 0)
       return Lz4Mode::Far;
+    if (e && std::strcmp(e, "farw") == 0)
+      return Lz4Mode::FarWide;
     return Lz4Mode::Auto;
   }();
   return mode;
@@ -2106,7 +2119,7 @@ hipError_t lz4_launch_compress(
   // it needs the ticket counter, and pays once the batch is more than the mix
   // shape has in flight at once (whose waves are the faster ones)
   const bool far_possible = scratch != nullptr && far_tables != nullptr && far.groups > 0;
-  if (mode == Lz4Mode::Far && !far_possible) // (forced by the environment)
+  if ((mode == Lz4Mode::Far || mode == Lz4Mode::FarWide) && !far_possible) // (forced by the environment)
     mode = Lz4Mode::Mix;
   if (mode == Lz4Mode::Auto
       && !(far_possible && far.groups * far.waves() > mix.groups * mix.waves() && batch > (size_t)mix.groups * mix.waves()))
@@ -2117,7 +2130,7 @@ hipError_t lz4_launch_compress(
   uint32_t* ticket = scratch;
   const uint32_t* chosen = nullptr; // the sampling kernel's counters, if it runs
   if (scratch) {
-    const hipError_t e = hipMemsetAsync(scratch, 0, 3 * sizeof(uint32_t), stream);
+    const hipError_t e = hipMemsetAsync(scratch, 0, 4 * sizeof(uint32_t), stream);
     if (e != hipSuccess)
       return e;
     if (mode == Lz4Mode::Auto) {
@@ -2135,17 +2148,18 @@ hipError_t lz4_launch_compress(
       per_ticket *= 2;
     return per_ticket;
   };
-  if (mode != Lz4Mode::Far) {
+  if (mode != Lz4Mode::Far && mode != Lz4Mode::FarWide) {
     // ticket == nullptr: no persistent workgroups, one chunk per wave
     const dim3 grid(ticket ? mix.groups : (unsigned)((batch + mix.waves() - 1) / mix.waves()));
     mix_kernel_for(elem_size)<<<grid, dim3(mix.waves() * kWave), mix.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
         (uint32_t)batch, ticket, chunks_per_ticket(mix), chosen);
   }
-  if (mode != Lz4Mode::Mix)
-    far_kernel_for(elem_size)<<<dim3(far.groups), dim3(far.waves() * kWave), far.lds_bytes, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, (uint32_t)batch, ticket,
-        chunks_per_ticket(far), chosen);
+  for (int wide = 0; wide < 2; ++wide)
+    if (mode == Lz4Mode::Auto || mode == (wide ? Lz4Mode::FarWide : Lz4Mode::Far))
+      far_kernel_for(elem_size, wide != 0)<<<dim3(far.groups), dim3(far.waves() * kWave), far.lds_bytes, stream>>>(
+          in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, (uint32_t)batch, ticket,
+          chunks_per_ticket(far), chosen);
   return hipSuccess;
 }
 

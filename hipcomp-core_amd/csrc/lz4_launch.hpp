@@ -32,14 +32,14 @@ struct Lz4CompressShape
 // the shape with the tables in LDS
 Lz4CompressShape lz4_compress_shape_mix(uint32_t ht_size, size_t batch);
 
-enum class Lz4Mode { Auto, Mix, Far };
-// HIPCOMP_LZ4_SHAPE = auto | mix | far (read once; default auto).  A
+enum class Lz4Mode { Auto, Mix, Far, FarWide };
+// HIPCOMP_LZ4_SHAPE = auto | mix | far | farw (read once; default auto).  A
 // measurement / test knob: the compressed bytes do not depend on it.
 Lz4Mode lz4_mode_from_environment();
 
-// `scratch` points at three zero-initialised-by-the-launcher uint32 in device
+// `scratch` points at four zero-initialised-by-the-launcher uint32 in device
 // memory (the head of the caller's temp buffer): the ticket counter from which
-// the waves of the persistent workgroups draw chunk numbers, and the two
+// the waves of the persistent workgroups draw chunk numbers, and the three
 // counters of the sampling kernel that pick the shape.  nullptr = one chunk per wave,
 // as many workgroups as that takes, "mix" shape.  `far_tables`: 16-byte aligned
 // device memory for far_capacity hash tables of max(ht_size, 8) uint16 each

@@ -29,7 +29,7 @@ def test_compiler_leaves_the_accumulation_registers_alone(tmp_path):
     vgprs = dict(re.findall(r"\.set (\S*lz4_compress_kernel_\S*)\.num_vgpr, (\d+)", text))
     mix = [k for k in agprs if "kernel_mix" in k]
     far = [k for k in agprs if "kernel_far" in k]
-    assert len(mix) == 3 and len(far) == 3       # element size 1, 2, 4
+    assert len(mix) == 3 and len(far) == 6       # element size 1, 2, 4 (far: lean and wide form)
     assert {agprs[k] for k in mix} == {"24"}     # the walk's own, nothing of the compiler's
     assert {agprs[k] for k in far} == {"0"}      # no walk
     assert all(int(vgprs[k]) <= 64 for k in far)     # 32 waves per CU = eight on one SIMD

@@ -48,6 +48,13 @@ __device__ __forceinline__ uint32_t snap_hash(uint32_t v)
 
 // lanes of a window whose table candidates the encoder fetches before the others'
 constexpr int kFirstLanes = 8;
+// bytes a window must have ahead of it for the straight path (the window's words
+// of all lanes, the general Match60 behind it)
+constexpr uint32_t kStraightMargin = 64 + 8 + 64 + 8;
+// the straight path moves on by at most 7 literals + 15 bytes of match and looks
+// at the words of lanes 0..19: these come from the window before
+constexpr uint32_t kStraightReach = 7 + 15;
+static_assert(19 + kStraightReach < 64, "the straight path's lanes must be inside the window before");
 
 __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     const uint8_t* const* __restrict__ in_ptrs,
@@ -102,17 +109,110 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     }
     pos = len;
   }
+  // Words of the window at `pos` from memory, asked for as soon as `pos` is
+  // known (`next`), and the words the straight path works on (`wnd`): those of
+  // `next` the first time, from then on the words of the window before moved
+  // down by the bytes the element took (ds_bpermute; the lanes that path looks
+  // at are all there), so that the load is off the chain from element to element.
+  uint32_t next = len >= 4 ? load_u32_any(src + min((uint32_t)lane, last_word)) : 0;
+  uint32_t wnd = next;
   while (pos < len) {
-    // ---- FindFourByteMatch (reference :190-246)
     const uint32_t pos0 = pos;
+    uint32_t copy_len = 0, distance = 0, lit = 0;
+    bool straight = false;
+    // ---- The common window of data that compresses, in a straight line
+    // (reference FindFourByteMatch :190-246, Match60 :251-269, StoreLiterals /
+    // StoreCopy :73-151): the first hit is a table candidate of one of the first
+    // 8 lanes, no two of which have the same hash, and the match is shorter than
+    // 16 bytes.  One trip to memory: 16 bytes at the candidates of the 8 lanes,
+    // which hold the match length as well; literals come from the window's
+    // registers.  The hash-map update is made for all 8 lanes at once (it is also
+    // the test for equal hashes: the highest lane of a slot survives) and taken
+    // back for the lanes behind the hit.
+    if (pos0 + kStraightMargin <= len) {
+      const uint32_t my = pos0 + (uint32_t)lane;
+      const uint32_t data32 = wnd;
+      const uint32_t hash = snap_hash(data32);
+      uint32_t h_old = 0, posted = my & 0xFFFFu;
+      bool tprobe = false;
+      uint32_t toff = 0;
+      u32x4 cand = {~data32, 0, 0, 0};
+      if (lane < kFirstLanes) {
+        h_old = hash_map[hash];
+        toff = (pos0 & ~0xffffu) | h_old;
+        if (toff >= pos0)
+          toff = (toff >= 0x10000u) ? toff - 0x10000u : pos0;
+        tprobe = toff < pos0 && toff + kMaxCopyDistance >= my;
+        if (tprobe)
+          cand = load_u128_any(src + toff);
+        lds_lane_exchange_fence();
+        hash_map[hash] = (uint16_t)my;
+        lds_lane_exchange_fence();
+        posted = hash_map[hash];
+        lds_lane_exchange_fence();
+      }
+      const uint64_t shared = wave_ballot(posted != (my & 0xFFFFu)); // a higher lane of the 8 has my hash
+      const uint64_t hits = wave_ballot(tprobe && cand.x == data32);
+      bool done = false;
+      if (shared == 0 && hits != 0) {
+        const int t = __builtin_ctzll(hits); // < 8
+        // match length from the candidate's bytes 4..15 against the words of
+        // lanes t + 4, t + 8, t + 12
+        const uint32_t x1 = read_lane(cand.y, t) ^ read_lane(data32, t + 4);
+        const uint32_t x2 = read_lane(cand.z, t) ^ read_lane(data32, t + 8);
+        const uint32_t x3 = read_lane(cand.w, t) ^ read_lane(data32, t + 12);
+        if ((x1 | x2 | x3) != 0) {
+          const uint32_t extra = x1 ? (uint32_t)__builtin_ctz(x1) >> 3
+                                    : x2 ? 4u + ((uint32_t)__builtin_ctz(x2) >> 3) : 8u + ((uint32_t)__builtin_ctz(x3) >> 3);
+          done = true;
+          lit = (uint32_t)t;
+          copy_len = 4u + extra;
+          distance = read_lane(my - toff, t);
+          if (lane < kFirstLanes && lane > t)
+            hash_map[hash] = (uint16_t)h_old;
+          // the element: [literal tag, literals] copy element, <= 1 + 7 + 3 bytes
+          uint32_t copy_tag, copy_bytes;
+          if (copy_len < 12 && distance < 2048) {
+            copy_tag = (((distance & 0x700u) >> 3) | ((copy_len - 4) << 2) | 0x01u) | ((distance & 0xFFu) << 8);
+            copy_bytes = 2;
+          } else {
+            copy_tag = (((copy_len - 1) << 2) | 0x2u) | (distance << 8);
+            copy_bytes = 3;
+          }
+          const uint32_t hdr = lit > 0 ? 1u : 0u;
+          const uint32_t cb = hdr + lit;
+          const uint32_t i = (uint32_t)lane;
+          // row_shr:1 -- lane i reads lane i - 1
+          const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)data32, 0x111, 0xF, 0xF, false);
+          uint32_t b = (lit - 1u) << 2;
+          if (i >= hdr && i < cb)
+            b = below;
+          if (i >= cb)
+            b = copy_tag >> (8u * (i - cb));
+          if (i < cb + copy_bytes)
+            dst[c + i] = (uint8_t)b;
+          c += cb + copy_bytes;
+          const uint32_t moved = lit + copy_len; // <= kStraightReach
+          pos = pos0 + moved;
+          wnd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + moved) & 63u) * 4u), (int)next);
+          next = load_u32_any(src + min(pos + (uint32_t)lane, last_word));
+          straight = true;
+        }
+      }
+      if (!done && lane < kFirstLanes)
+        hash_map[hash] = (uint16_t)h_old;
+      lds_lane_exchange_fence();
+    }
+    if (straight)
+      continue;
+    // ---- FindFourByteMatch (reference :190-246)
     const uint32_t maxpos = pos0 + kMaxLiteral - (kWave - 1);
     uint32_t p = pos0;
-    uint32_t copy_len = 0, distance = 0;
     uint32_t literal_cnt;
     do {
       const uint32_t my = p + (uint32_t)lane;
       const bool valid4 = my + 4 <= len;
-      const uint32_t raw = load_u32_any(src + min(my, last_word));
+      const uint32_t raw = p == pos0 ? next : load_u32_any(src + min(my, last_word));
       const uint32_t data32 = valid4 ? raw : 0;
       const uint32_t hash = valid4 ? snap_hash(data32) : 0;
 
@@ -185,7 +285,7 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         hash_map[hash] = (uint16_t)my;
       p += literal_cnt;
     } while (literal_cnt == kWave && p < maxpos);
-    const uint32_t lit = min(p, len) - pos0;
+    lit = min(p, len) - pos0;
 
     // ---- Match60 (reference :251-269)
     if (copy_len) {
@@ -240,6 +340,8 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
       c += copy_bytes;
     }
     pos = pos0 + lit + copy_len;
+    next = load_u32_any(src + min(pos + (uint32_t)lane, last_word));
+    wnd = next;
   }
   if (lane == 0)
     out_bytes[chunk] = c;

@@ -72,8 +72,8 @@ constexpr uint32_t kStageWords = 8 * kWave; // 2 KiB
 template <int S, int CB>
 __host__ __device__ constexpr uint32_t dec_lds_bytes()
 {
-  // two element buffers + run starts + run markers + staged sub-chunk
-  return 2 * elem_buf_bytes<CB>() + 2 * (CB / S) * 2 + kStageWords * 4;
+  // two element buffers + run markers + staged sub-chunk
+  return 2 * elem_buf_bytes<CB>() + (CB / S) * 2 + kStageWords * 4;
 }
 
 // ---- wave reductions (64 lanes) -------------------------------------------
@@ -427,6 +427,58 @@ __device__ __forceinline__ int unpack_array(
   return (int)n;
 }
 
+// The same array, element by element (for a pass that uses the values at once
+// instead of parking them in LDS).  open() returns the element count or -1.
+template <typename ET, typename WordPtr>
+struct ArrayReader {
+  static constexpr uint32_t ES = sizeof(ET);
+  WordPtr data;
+  uint32_t bw, last, fr;
+  int bp;
+  __device__ __forceinline__ int open(WordPtr src, uint32_t nbytes, int bp_, uint32_t max_elems)
+  {
+    static_assert(ES <= 4, "run lengths are 16-bit");
+    bp = bp_;
+    if (!bp) {
+      const uint32_t n = nbytes / ES;
+      data = src;
+      return n > max_elems ? -1 : (int)n;
+    }
+    if (nbytes < 8)
+      return -1;
+    fr = uniform((uint32_t)src[0]);
+    const uint32_t word = uniform((uint32_t)src[1]);
+    bw = word >> 16;
+    const uint32_t n = word & 0xFFFFu;
+    if (n == 0)
+      return 0;
+    if (n > max_elems || bw > 8 * ES)
+      return -1;
+    const uint32_t words = (n * bw + 31) / 32;
+    if (8 + 4 * words > ru(nbytes, 4))
+      return -1;
+    data = src + 2;
+    last = words - 1;
+    return (int)n;
+  }
+  // element i (< the count open() returned)
+  __device__ __forceinline__ ET get(uint32_t i) const
+  {
+    if (!bp) {
+      const uint32_t b = i * ES;
+      return (ET)((uint32_t)data[b >> 2] >> (8u * (b & 3u)));
+    }
+    uint32_t x = 0;
+    if (bw) {
+      const uint32_t bit = i * bw;
+      const uint32_t w0 = bit >> 5, sh = bit & 31u;
+      const uint64_t lo = (uint64_t)data[w0] | ((uint64_t)data[min(w0 + 1, last)] << 32);
+      x = (uint32_t)(lo >> sh) & (uint32_t)((1ull << bw) - 1ull);
+    }
+    return (ET)(x + fr);
+  }
+};
+
 // Array at byte offset `rel` of the sub-chunk that starts at comp + pos:
 // bounds as in the reference (:712-713), source = staged image when the array
 // lies inside it.
@@ -544,9 +596,8 @@ __device__ __forceinline__ void cascaded_decode_partition(
   uint8_t* my = smem;
   UT* bufA = reinterpret_cast<UT*>(my);
   UT* bufB = reinterpret_cast<UT*>(my + elem_buf_bytes<CB>());
-  uint16_t* cnts = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes<CB>());
-  uint16_t* marks = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes<CB>() + (CB / S) * 2);
-  uint32_t* stage = reinterpret_cast<uint32_t*>(my + 2 * elem_buf_bytes<CB>() + 2 * (CB / S) * 2);
+  uint16_t* marks = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes<CB>());
+  uint32_t* stage = reinterpret_cast<uint32_t*>(my + 2 * elem_buf_bytes<CB>() + (CB / S) * 2);
   const uint32_t* meta = stage; // the chunk metadata is the head of the staged image
 
   constexpr uint32_t CE = CB / S;
@@ -648,14 +699,11 @@ __device__ __forceinline__ void cascaded_decode_partition(
         uint32_t o = 0;
         for (int i = 0; i < l; ++i)
           o = ru(o + uniform(meta[i + 1]), 4u);
-        const int m = wave_read_array<uint16_t>(comp, end_w, pos, msz + o, uniform(meta[l + 1]), bp, stage, cnts, CE, lane);
-        if (m < 0 || m != n) {
-          ok = false;
-          break;
-        }
         // Each run drops its index+1 at its start position (exclusive prefix
         // of the lengths) in `marks`; a running max over the positions then
-        // names the run of every output element.
+        // names the run of every output element.  The lengths are used as they
+        // come out of the packed array (reference block_read :702-737 +
+        // block_bitunpack :563-618; bounds as :712-713).
         {
           u32x4 z = {0, 0, 0, 0};
           u32x4* mz = reinterpret_cast<u32x4*>(marks);
@@ -664,15 +712,37 @@ __device__ __forceinline__ void cascaded_decode_partition(
         }
         uint32_t carry = 0;
         bool too_long = false;
-        for (uint32_t b0 = 0; b0 < (uint32_t)n; b0 += kWave) {
-          const uint32_t i = b0 + (uint32_t)lane;
-          const uint32_t cv = i < (uint32_t)n ? cnts[i] : 0u;
-          const uint32_t incl = wave_scan_add_u32(cv);
-          const uint32_t start = carry + incl - cv;
-          carry += read_lane(incl, 63);
-          if (i < (uint32_t)n && start < CE)
-            marks[start] = (uint16_t)(i + 1);
-          too_long = too_long || carry > CE;
+        auto run_starts = [&](auto words) {
+          ArrayReader<uint16_t, decltype(words)> lengths;
+          const int m = lengths.open(words, uniform(meta[l + 1]), bp, CE);
+          if (m < 0 || m != n)
+            return false;
+          for (uint32_t b0 = 0; b0 < (uint32_t)n; b0 += kWave) {
+            const uint32_t i = b0 + (uint32_t)lane;
+            const uint32_t cv = i < (uint32_t)n ? (uint32_t)lengths.get(i) : 0u;
+            const uint32_t incl = wave_scan_add_u32(cv);
+            const uint32_t start = carry + incl - cv;
+            carry += read_lane(incl, 63);
+            if (i < (uint32_t)n && start < CE)
+              marks[start] = (uint16_t)(i + 1);
+            too_long = too_long || carry > CE;
+          }
+          return true;
+        };
+        {
+          const uint32_t rel = msz + o, nbytes = uniform(meta[l + 1]);
+          const uint32_t off = pos + rel;
+          bool good = !((off & 3u) || (off + ru(nbytes, 4)) / 4 > end_w);
+          if (good) {
+            if (rel + ru(nbytes, 4) <= kStageWords * 4)
+              good = run_starts(static_cast<const uint32_t*>(stage + rel / 4));
+            else
+              good = run_starts(reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off));
+          }
+          if (!good) {
+            ok = false;
+            break;
+          }
         }
         if (too_long) {
           ok = false;

@@ -164,10 +164,11 @@ def _splitmix(x):
     return x ^ ((x >> 31) & ((1 << 33) - 1))
 
 
-def gen_sorted_columns(n_parts: int, device, seed: int = 0x5EED0005):
+def gen_sorted_columns(n_parts: int, device, seed: int = 0x5EED0005, inc_bits: int = 3):
     """Config 3: one sorted uint32 column per 64 KiB partition; v[0] ~ U[0, 2^20),
     v[i] = v[i-1] + (g == 0 ? 0 : U[1, 8]), g ~ U[0, 4) (about 25 % repeats);
-    partition i draws from the counter-based stream of seed + i."""
+    partition i draws from the counter-based stream of seed + i.  inc_bits other than 3: steps of
+    U[1, 2^inc_bits] (less compressible columns for measurements; not a BASELINE config)."""
     import torch
     per = CHUNK // 4
     out = torch.empty(n_parts * per, dtype=torch.int32, device=device)
@@ -178,7 +179,7 @@ def gen_sorted_columns(n_parts: int, device, seed: int = 0x5EED0005):
         s = (torch.arange(p0, p1, dtype=torch.int64, device=device) + seed)[:, None]
         r = _splitmix((s << 20) + j[None, :])
         g = r & 3
-        inc = torch.where(g == 0, torch.zeros_like(r), ((r >> 8) & 7) + 1)
+        inc = torch.where(g == 0, torch.zeros_like(r), ((r >> 8) & ((1 << inc_bits) - 1)) + 1)
         inc[:, 0] = (r[:, 0] >> 16) & ((1 << 20) - 1)
         v = torch.cumsum(inc, dim=1)
         # every 1024-element sub-chunk holds at least two distinct values, so

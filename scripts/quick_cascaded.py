@@ -10,10 +10,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--parts", type=int, default=100000)
 ap.add_argument("--chunk-size", default="4096")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--inc-bits", type=int, default=3, help="steps of U[1, 2^n]: 3 = BASELINE config 3, more = less compressible")
 a = ap.parse_args()
 hc = importlib.import_module("hipcomp-core_amd")
 dev = torch.device("cuda:0")
-cols = bench.gen_sorted_columns(a.parts, dev)
+cols = bench.gen_sorted_columns(a.parts, dev, inc_bits=a.inc_bits)
 for cb in [int(x) for x in a.chunk_size.split(",")]:
     job = bench.CodecJob(hc, hc.default_library(), "Cascaded", hc.CascadedOpts(cb, hc.hipcompType.UINT, 2, 1, 1), cols)
     job.compress(); job.decompress(); torch.cuda.synchronize()

@@ -51,10 +51,11 @@ constexpr int kFirstLanes = 8;
 // bytes a window must have ahead of it for the straight path (the window's words
 // of all lanes, the general Match60 behind it)
 constexpr uint32_t kStraightMargin = 64 + 8 + 64 + 8;
-// the straight path moves on by at most 7 literals + 15 bytes of match and looks
-// at the words of lanes 0..19: these come from the window before
-constexpr uint32_t kStraightReach = 7 + 15;
-static_assert(19 + kStraightReach < 64, "the straight path's lanes must be inside the window before");
+// lanes whose candidates one trip of the straight path fetches; it looks at the
+// words of lanes 0..kSpan+11, which come from the window before if the elements
+// moved on by no more than kStraightReach bytes
+constexpr int kSpan = 24;
+constexpr uint32_t kStraightReach = 64 - (kSpan + 12);
 
 __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     const uint8_t* const* __restrict__ in_ptrs,
@@ -120,88 +121,126 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     const uint32_t pos0 = pos;
     uint32_t copy_len = 0, distance = 0, lit = 0;
     bool straight = false;
-    // ---- The common window of data that compresses, in a straight line
+    // ---- The common stretch of data that compresses, in a straight line
     // (reference FindFourByteMatch :190-246, Match60 :251-269, StoreLiterals /
-    // StoreCopy :73-151): the first hit is a table candidate of one of the first
-    // 8 lanes, no two of which have the same hash, and the match is shorter than
-    // 16 bytes.  One trip to memory: 16 bytes at the candidates of the 8 lanes,
-    // which hold the match length as well; literals come from the window's
-    // registers.  The hash-map update is made for all 8 lanes at once (it is also
-    // the test for equal hashes: the highest lane of a slot survives) and taken
-    // back for the lanes behind the hit.
+    // StoreCopy :73-151).  ONE trip to memory serves several elements: the first
+    // kSpan lanes look their candidates up and fetch 16 bytes there, which hold
+    // the match length as well if the match is shorter than 16 bytes; then the
+    // elements are taken off one after the other (the next one's window starts
+    // where the match ended, its first hit is the next lane with a hit) for as
+    // long as they stay inside those lanes.  Literals come from the window's
+    // registers.  The hash-map update is posted for all kSpan lanes at once --
+    // the read-back is also the test for equal hashes: the highest lane of a
+    // slot survives, so a lane that reads another lane's position has a higher
+    // lane with its hash, and the elements stop in front of such a lane (its
+    // candidate, and what the lanes above it would have to see, are not what
+    // this path assumes) -- and afterwards set right: only the lanes up to each
+    // hit stay.  Whatever else a window holds is left to the general code below
+    // with the hash map as it was.
     if (pos0 + kStraightMargin <= len) {
       const uint32_t my = pos0 + (uint32_t)lane;
       const uint32_t data32 = wnd;
       const uint32_t hash = snap_hash(data32);
-      uint32_t h_old = 0, posted = my & 0xFFFFu;
-      bool tprobe = false;
-      uint32_t toff = 0;
-      u32x4 cand = {~data32, 0, 0, 0};
-      if (lane < kFirstLanes) {
+      // the words 4, 8 and 12 bytes on
+      const uint32_t d1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 4u) & 63u) * 4, (int)data32);
+      const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 8u) & 63u) * 4, (int)data32);
+      const uint32_t d3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 12u) & 63u) * 4, (int)data32);
+      uint32_t h_old = 0;
+      uint32_t code = 0; // 1: a match shorter than 16 bytes, 3: a longer one, 2: a higher lane has my hash
+      uint32_t extra = 0, dist = 0;
+      if (lane < kSpan) {
         h_old = hash_map[hash];
-        toff = (pos0 & ~0xffffu) | h_old;
+        uint32_t toff = (pos0 & ~0xffffu) | h_old;
         if (toff >= pos0)
           toff = (toff >= 0x10000u) ? toff - 0x10000u : pos0;
-        tprobe = toff < pos0 && toff + kMaxCopyDistance >= my;
+        const bool tprobe = toff < pos0 && toff + kMaxCopyDistance >= my;
+        u32x4 cand = {~data32, 0, 0, 0};
         if (tprobe)
           cand = load_u128_any(src + toff);
         lds_lane_exchange_fence();
         hash_map[hash] = (uint16_t)my;
         lds_lane_exchange_fence();
-        posted = hash_map[hash];
+        const uint32_t posted = hash_map[hash];
         lds_lane_exchange_fence();
+        dist = my - toff;
+        // first differing byte among bytes 4..15 of the match (v_ffbl_b32: -1 for 0)
+        uint32_t f1, f2, f3;
+        asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(cand.y ^ d1));
+        asm("v_ffbl_b32 %0, %1" : "=v"(f2) : "v"(cand.z ^ d2));
+        asm("v_ffbl_b32 %0, %1" : "=v"(f3) : "v"(cand.w ^ d3));
+        extra = min(min(f1, f2 | 32u), f3 | 64u) >> 3; // 0..11, or all 12 bytes equal
+        code = (tprobe && cand.x == data32) ? (extra < 12u ? 1u : 3u) : 0u;
+        code = posted != (my & 0xFFFFu) ? 2u : code;
       }
-      const uint64_t shared = wave_ballot(posted != (my & 0xFFFFu)); // a higher lane of the 8 has my hash
-      const uint64_t hits = wave_ballot(tprobe && cand.x == data32);
-      bool done = false;
-      if (shared == 0 && hits != 0) {
-        const int t = __builtin_ctzll(hits); // < 8
-        // match length from the candidate's bytes 4..15 against the words of
-        // lanes t + 4, t + 8, t + 12
-        const uint32_t x1 = read_lane(cand.y, t) ^ read_lane(data32, t + 4);
-        const uint32_t x2 = read_lane(cand.z, t) ^ read_lane(data32, t + 8);
-        const uint32_t x3 = read_lane(cand.w, t) ^ read_lane(data32, t + 12);
-        if ((x1 | x2 | x3) != 0) {
-          const uint32_t extra = x1 ? (uint32_t)__builtin_ctz(x1) >> 3
-                                    : x2 ? 4u + ((uint32_t)__builtin_ctz(x2) >> 3) : 8u + ((uint32_t)__builtin_ctz(x3) >> 3);
-          done = true;
-          lit = (uint32_t)t;
-          copy_len = 4u + extra;
-          distance = read_lane(my - toff, t);
-          if (lane < kFirstLanes && lane > t)
-            hash_map[hash] = (uint16_t)h_old;
-          // the element: [literal tag, literals] copy element, <= 1 + 7 + 3 bytes
-          uint32_t copy_tag, copy_bytes;
-          if (copy_len < 12 && distance < 2048) {
-            copy_tag = (((distance & 0x700u) >> 3) | ((copy_len - 4) << 2) | 0x01u) | ((distance & 0xFFu) << 8);
-            copy_bytes = 2;
-          } else {
-            copy_tag = (((copy_len - 1) << 2) | 0x2u) | (distance << 8);
-            copy_bytes = 3;
-          }
-          const uint32_t hdr = lit > 0 ? 1u : 0u;
-          const uint32_t cb = hdr + lit;
-          const uint32_t i = (uint32_t)lane;
-          // row_shr:1 -- lane i reads lane i - 1
-          const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)data32, 0x111, 0xF, 0xF, false);
-          uint32_t b = (lit - 1u) << 2;
-          if (i >= hdr && i < cb)
-            b = below;
-          if (i >= cb)
-            b = copy_tag >> (8u * (i - cb));
-          if (i < cb + copy_bytes)
-            dst[c + i] = (uint8_t)b;
-          c += cb + copy_bytes;
-          const uint32_t moved = lit + copy_len; // <= kStraightReach
-          pos = pos0 + moved;
-          wnd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + moved) & 63u) * 4u), (int)next);
-          next = load_u32_any(src + min(pos + (uint32_t)lane, last_word));
-          straight = true;
+      const uint64_t events = wave_ballot(code != 0);
+      uint32_t start = 0;   // lane at which the next element's window starts
+      uint64_t stay = 0;    // lanes whose hash-map update stays
+      while (true) {
+        const uint64_t ev = events & ~((1ull << start) - 1ull);
+        if (ev == 0)
+          break;
+        const int t = __builtin_ctzll(ev);
+        const uint32_t code_t = read_lane(code, t);
+        if ((code_t & 1u) == 0)
+          break;
+        lit = (uint32_t)t - start;
+        uint32_t xt = read_lane(extra, t); // copy length - 4
+        distance = read_lane(dist, t);
+        if (code_t == 3u) { // Match60 (reference :251-269; 60 bytes are there)
+          const uint32_t match_pos = pos0 + (uint32_t)t + 4;
+          bool mis = true;
+          if (lane < 60)
+            mis = src[match_pos + lane] != src[match_pos - distance + lane];
+          xt = (uint32_t)__builtin_ctzll(wave_ballot(mis));
         }
+        // the element: [literal tag, literals] copy element, <= 1 + 23 + 3 bytes
+        const bool two = xt < 8u && distance < 2048u;
+        const uint32_t tag2 = (((distance & 0x700u) >> 3) | (xt << 2) | 0x01u) | ((distance & 0xFFu) << 8);
+        const uint32_t tag3 = (((xt + 3u) << 2) | 0x2u) | (distance << 8);
+        const uint32_t copy_tag = two ? tag2 : tag3;
+        const uint32_t copy_bytes = two ? 2u : 3u;
+        const uint32_t hdr = lit > 0 ? 1u : 0u;
+        const uint32_t cb = hdr + lit;
+        const uint32_t i = (uint32_t)lane;
+        uint32_t b = (lit - 1u) << 2;
+        if (lit > 0) {
+          const uint32_t below = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((start + i - 1u) & 63u) * 4, (int)data32);
+          if (i >= 1u && i < cb)
+            b = below;
+        }
+        if (i >= cb)
+          b = copy_tag >> (8u * (i - cb));
+        if (i < cb + copy_bytes)
+          dst[c + i] = (uint8_t)b;
+        c += cb + copy_bytes;
+        stay |= ((2ull << t) - 1ull) & ~((1ull << start) - 1ull); // lanes start..t
+        start = (uint32_t)t + 4u + xt;
+        if (start >= 64u)
+          break;
       }
-      if (!done && lane < kFirstLanes)
+      // the hash map as the elements leave it: every other lane takes its update
+      // back, then the lanes that stay post theirs again (a lane inside a match
+      // may have shared its slot with one of them)
+      const bool stays = ((stay >> lane) & 1ull) != 0;
+      if (lane < kSpan && !stays)
         hash_map[hash] = (uint16_t)h_old;
       lds_lane_exchange_fence();
+      if (stays)
+        hash_map[hash] = (uint16_t)my;
+      lds_lane_exchange_fence();
+      if (start != 0) {
+        const uint32_t moved = start;
+        pos = pos0 + moved;
+        const uint32_t moved_words = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + moved) & 63u) * 4u), (int)next);
+        next = load_u32_any(src + min(pos + (uint32_t)lane, last_word));
+        wnd = moved_words;
+        if (__builtin_expect(moved > kStraightReach, 0)) {
+          // (a real branch: as a select it would make every trip wait for the load)
+          asm volatile("" ::: "memory");
+          wnd = next;
+        }
+        straight = true;
+      }
     }
     if (straight)
       continue;

@@ -54,7 +54,10 @@ constexpr uint32_t kStraightMargin = 64 + 8 + 64 + 8;
 // lanes whose candidates one trip of the straight path fetches; it looks at the
 // words of lanes 0..kSpan+11, which come from the window before if the elements
 // moved on by no more than kStraightReach bytes
-constexpr int kSpan = 24;
+#ifndef HC_SNAPPY_SPAN
+#define HC_SNAPPY_SPAN 24 // (measurement builds: 16..40)
+#endif
+constexpr int kSpan = HC_SNAPPY_SPAN;
 constexpr uint32_t kStraightReach = 64 - (kSpan + 12);
 
 __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
@@ -146,8 +149,11 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
       const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 8u) & 63u) * 4, (int)data32);
       const uint32_t d3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 12u) & 63u) * 4, (int)data32);
       uint32_t h_old = 0;
-      uint32_t code = 0; // 1: a match shorter than 16 bytes, 3: a longer one, 2: a higher lane has my hash
-      uint32_t extra = 0, dist = 0;
+      // what a lane says about itself, in one word: bits 30-31 code (1: a match
+      // shorter than 16 bytes, 3: a longer one, 2: a higher lane has my hash),
+      // 26-29 copy length - 4, 24-25 bytes of the copy element, 0-23 those bytes
+      uint32_t word_of_lane = 0;
+      uint32_t dist = 0;
       if (lane < kSpan) {
         h_old = hash_map[hash];
         uint32_t toff = (pos0 & ~0xffffu) | h_old;
@@ -168,37 +174,40 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(cand.y ^ d1));
         asm("v_ffbl_b32 %0, %1" : "=v"(f2) : "v"(cand.z ^ d2));
         asm("v_ffbl_b32 %0, %1" : "=v"(f3) : "v"(cand.w ^ d3));
-        extra = min(min(f1, f2 | 32u), f3 | 64u) >> 3; // 0..11, or all 12 bytes equal
-        code = (tprobe && cand.x == data32) ? (extra < 12u ? 1u : 3u) : 0u;
+        const uint32_t extra = min(min(min(f1, f2 | 32u), f3 | 64u) >> 3, 12u); // 0..11, 12: all 12 bytes equal
+        uint32_t code = (tprobe && cand.x == data32) ? (extra < 12u ? 1u : 3u) : 0u;
         code = posted != (my & 0xFFFFu) ? 2u : code;
+        // the copy element (reference StoreCopy :118-151)
+        const bool two = (int32_t)((extra - 8u) & (dist - 2048u)) < 0; // extra < 8 and dist < 2048
+        const uint32_t tag2 = (((dist & 0x700u) >> 3) | (extra << 2) | 0x01u) | ((dist & 0xFFu) << 8) | (2u << 24);
+        const uint32_t tag3 = (((extra + 3u) << 2) | 0x2u) | ((dist & 0xFFFFu) << 8) | (3u << 24);
+        word_of_lane = (two ? tag2 : tag3) | (extra << 26) | (code << 30);
       }
-      const uint64_t events = wave_ballot(code != 0);
+      const uint64_t events = wave_ballot(word_of_lane >= (1u << 30));
       uint32_t start = 0;   // lane at which the next element's window starts
       uint64_t stay = 0;    // lanes whose hash-map update stays
       while (true) {
-        const uint64_t ev = events & ~((1ull << start) - 1ull);
+        const uint64_t ev = events >> start;
         if (ev == 0)
           break;
-        const int t = __builtin_ctzll(ev);
-        const uint32_t code_t = read_lane(code, t);
-        if ((code_t & 1u) == 0)
+        const int t = (int)start + __builtin_ctzll(ev);
+        const uint32_t about = read_lane(word_of_lane, t);
+        if ((about & (1u << 30)) == 0)
           break;
         lit = (uint32_t)t - start;
-        uint32_t xt = read_lane(extra, t); // copy length - 4
-        distance = read_lane(dist, t);
-        if (code_t == 3u) { // Match60 (reference :251-269; 60 bytes are there)
+        uint32_t xt = (about >> 26) & 15u; // copy length - 4
+        uint32_t copy_tag = about & 0xFFFFFFu, copy_bytes = (about >> 24) & 3u;
+        if (about >= (3u << 30)) { // Match60 (reference :251-269; 60 bytes are there)
+          distance = read_lane(dist, t);
           const uint32_t match_pos = pos0 + (uint32_t)t + 4;
           bool mis = true;
           if (lane < 60)
             mis = src[match_pos + lane] != src[match_pos - distance + lane];
           xt = (uint32_t)__builtin_ctzll(wave_ballot(mis));
+          copy_tag = (((xt + 3u) << 2) | 0x2u) | (distance << 8);
+          copy_bytes = 3;
         }
         // the element: [literal tag, literals] copy element, <= 1 + 23 + 3 bytes
-        const bool two = xt < 8u && distance < 2048u;
-        const uint32_t tag2 = (((distance & 0x700u) >> 3) | (xt << 2) | 0x01u) | ((distance & 0xFFu) << 8);
-        const uint32_t tag3 = (((xt + 3u) << 2) | 0x2u) | (distance << 8);
-        const uint32_t copy_tag = two ? tag2 : tag3;
-        const uint32_t copy_bytes = two ? 2u : 3u;
         const uint32_t hdr = lit > 0 ? 1u : 0u;
         const uint32_t cb = hdr + lit;
         const uint32_t i = (uint32_t)lane;

@@ -11,11 +11,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--chunks", type=int, default=16384)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--lib", default=None, help="another build of the library (measurement variants)")
 a = ap.parse_args()
 hc = importlib.import_module("hipcomp-core_amd")
 dev = torch.device("cuda:0")
 data = torch.from_numpy(bench.gen_text(a.chunks * bench.CHUNK)).to(dev)
-job = bench.CodecJob(hc, hc.default_library(), "Snappy", hc.SnappyOpts(0), data)
+lib = hc.HipcompLibrary(os.path.join(ROOT, a.lib)) if a.lib else hc.default_library()
+job = bench.CodecJob(hc, lib, "Snappy", hc.SnappyOpts(0), data)
 job.compress(); job.decompress(); torch.cuda.synchronize()
 job.verify()
 tc, td = bench.time_phases(job, a.reps)

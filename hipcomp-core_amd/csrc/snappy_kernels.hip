@@ -46,6 +46,14 @@ __device__ __forceinline__ uint32_t snap_hash(uint32_t v)
   return (v * ((1u << 20) + 0x2a00u + 0x6au + 1u)) >> (32 - kHashBits);
 }
 
+// lowest set bit, -1 for 0 (s_ff1_i32_b64 as it is; __builtin_ctzll(0) is undefined)
+__device__ __forceinline__ int first_set_or_minus_one(uint64_t m)
+{
+  int r;
+  asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m));
+  return r;
+}
+
 // lanes of a window whose table candidates the encoder fetches before the others'
 constexpr int kFirstLanes = 8;
 // bytes a window must have ahead of it for the straight path (the window's words
@@ -160,14 +168,16 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         if (toff >= pos0)
           toff = (toff >= 0x10000u) ? toff - 0x10000u : pos0;
         const bool tprobe = toff < pos0 && toff + kMaxCopyDistance >= my;
-        u32x4 cand = {~data32, 0, 0, 0};
-        if (tprobe)
-          cand = load_u128_any(src + toff);
+        // (a lane without a candidate reads the head of the chunk: no branch around the load)
+        u32x4 cand = load_u128_any(src + (tprobe ? toff : 0u));
         lds_lane_exchange_fence();
         hash_map[hash] = (uint16_t)my;
         lds_lane_exchange_fence();
-        const uint32_t posted = hash_map[hash];
+        uint32_t posted = hash_map[hash];
         lds_lane_exchange_fence();
+        // (the candidates are looked at only now: left to itself the compiler waits
+        // for them before it posts)
+        asm volatile("" : "+v"(cand.x), "+v"(cand.y), "+v"(cand.z), "+v"(cand.w), "+v"(posted));
         dist = my - toff;
         // first differing byte among bytes 4..15 of the match (v_ffbl_b32: -1 for 0)
         uint32_t f1, f2, f3;
@@ -184,20 +194,18 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         word_of_lane = (two ? tag2 : tag3) | (extra << 26) | (code << 30);
       }
       const uint64_t events = wave_ballot(word_of_lane >= (1u << 30));
-      uint32_t start = 0;   // lane at which the next element's window starts
-      uint64_t stay = 0;    // lanes whose hash-map update stays
-      while (true) {
-        const uint64_t ev = events >> start;
-        if (ev == 0)
-          break;
-        const int t = (int)start + __builtin_ctzll(ev);
-        const uint32_t about = read_lane(word_of_lane, t);
-        if ((about & (1u << 30)) == 0)
-          break;
+      // The elements, one after the other.  (One loop condition, and the lane
+      // select -1 of "no event" reads lane 63, whose word is 0: the compiler
+      // gives a loop with several exits a guard variable per exit.)
+      uint32_t start = 0;                        // lane at which the next element's window starts
+      uint64_t hit_lanes = 0, start_lanes = 0;   // (as bit sets) of the elements taken
+      int t = first_set_or_minus_one(events);
+      uint32_t about = read_lane(word_of_lane, t & 63);
+      while ((about & (1u << 30)) != 0) {
         lit = (uint32_t)t - start;
         uint32_t xt = (about >> 26) & 15u; // copy length - 4
         uint32_t copy_tag = about & 0xFFFFFFu, copy_bytes = (about >> 24) & 3u;
-        if (about >= (3u << 30)) { // Match60 (reference :251-269; 60 bytes are there)
+        if (__builtin_expect(about >= (3u << 30), 0)) { // Match60 (reference :251-269; 60 bytes are there)
           distance = read_lane(dist, t);
           const uint32_t match_pos = pos0 + (uint32_t)t + 4;
           bool mis = true;
@@ -207,26 +215,31 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
           copy_tag = (((xt + 3u) << 2) | 0x2u) | (distance << 8);
           copy_bytes = 3;
         }
-        // the element: [literal tag, literals] copy element, <= 1 + 23 + 3 bytes
-        const uint32_t hdr = lit > 0 ? 1u : 0u;
-        const uint32_t cb = hdr + lit;
-        const uint32_t i = (uint32_t)lane;
-        uint32_t b = (lit - 1u) << 2;
-        if (lit > 0) {
-          const uint32_t below = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((start + i - 1u) & 63u) * 4, (int)data32);
-          if (i >= 1u && i < cb)
-            b = below;
+        // the element -- [literal tag, literals] copy element, <= 1 + 23 + 3 bytes --
+        // in one store: the literal lanes write their own byte, the lane of the hit
+        // the literal tag, the lanes behind it the copy element
+        {
+          const uint32_t rel = (uint32_t)lane - start;
+          const uint32_t k = rel - lit - 1u;
+          const bool is_lit = rel < lit;
+          const bool is_tag = lit > 0 && rel == lit;
+          const bool is_copy = k < copy_bytes;
+          uint32_t val = is_lit ? data32 : copy_tag >> (8u * k);
+          val = is_tag ? (lit - 1u) << 2 : val;
+          uint32_t off = rel + (is_lit ? 1u : (lit > 0 ? 0u : ~0u));
+          off = is_tag ? 0u : off;
+          if (is_lit || is_tag || is_copy)
+            dst[c + off] = (uint8_t)val;
         }
-        if (i >= cb)
-          b = copy_tag >> (8u * (i - cb));
-        if (i < cb + copy_bytes)
-          dst[c + i] = (uint8_t)b;
-        c += cb + copy_bytes;
-        stay |= ((2ull << t) - 1ull) & ~((1ull << start) - 1ull); // lanes start..t
+        c += lit + (lit > 0 ? 1u : 0u) + copy_bytes;
+        asm("s_bitset1_b64 %0, %1" : "+s"(hit_lanes) : "s"(t));
+        asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
         start = (uint32_t)t + 4u + xt;
-        if (start >= 64u)
-          break;
+        t = first_set_or_minus_one(events & (~0ull << min(start, 63u))); // (bit 63 of events is never set)
+        about = read_lane(word_of_lane, t & 63);
       }
+      // lanes start..hit of every element: their hash-map update stays
+      const uint64_t stay = (hit_lanes << 1) - start_lanes;
       // the hash map as the elements leave it: every other lane takes its update
       // back, then the lanes that stay post theirs again (a lane inside a match
       // may have shared its slot with one of them)

@@ -1503,6 +1503,128 @@ __device__ __forceinline__ bool far_straight(
   return armed;
 }
 
+// ---------------------------------------------------------------------------
+// The lean form for byte elements, several sequences per trip to memory: the
+// first kFarSpan lanes look their table slots up and fetch 16 bytes at their
+// candidates -- they hold the match length of a match shorter than 16 bytes as
+// well -- and the sequences are then taken off one after the other in registers
+// (the next one's window starts where the match ended; its first table match is
+// the next lane with one) for as long as they stay inside those lanes.  A
+// sequence is taken if its literal lanes sit in table slots of their own (two
+// lanes with one word, the duplicate of reference :868-894, share one) and no
+// lane of its window up to the match sits in a slot that an earlier sequence of
+// the trip has written (what it looked up was read before that); the table is
+// written per sequence.  A window that is anything else is left to the caller.  Returns false if the window it
+// stopped at had no table match among those lanes at all.
+// ---------------------------------------------------------------------------
+constexpr int kFarSpan = 24;
+constexpr uint32_t kFarSpanReach = 64 - (kFarSpan + 12); // bytes the window's words can move down by
+
+__device__ __forceinline__ int first_set_or_minus_one(uint64_t m) // (s_ff1_i32_b64 as it is)
+{
+  int r;
+  asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m));
+  return r;
+}
+
+__device__ __forceinline__ bool far_straight_bytes(
+    cgptr __restrict__ in, gptr __restrict__ out, HC_GLOBAL uint16_t* const table,
+    const uint32_t hmask, const uint32_t L, const uint32_t last_word, const int lane, uint32_t& d, uint32_t& c,
+    uint32_t& token_start, int& cold, uint32_t& next)
+{
+  uint32_t wnd = next;
+  bool armed = true;
+  while (d + kFarFastMargin <= L) {
+    const uint32_t word = wnd;
+    const uint32_t hpos = hash_sum(word) & hmask;
+    const uint32_t pos = d + (uint32_t)lane;
+    // the words 4, 8 and 12 bytes on
+    const uint32_t d1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 4u) & 63u) * 4, (int)word);
+    const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 8u) & 63u) * 4, (int)word);
+    const uint32_t d3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 12u) & 63u) * 4, (int)word);
+    // what a lane says about its table match, in one word: bit 30 set: there is
+    // one, bit 31: of 16 bytes or more, 26-29 match length - 4, 0-15 the offset
+    uint32_t about = 0;
+    if (lane < kFarSpan) {
+      const uint32_t h_old = table[hpos];
+      const uint32_t back = (pos - 1u - h_old) & 0xFFFFu; // (see window_candidate)
+      const uint32_t cand = pos - 1u - back;
+      const bool usable = (h_old != kNullOffset) & (back < 65535u);
+      const u32x4 cw = load_u128_any(in + (usable ? cand : 0u));
+      // first differing byte among bytes 4..15 of the match (v_ffbl_b32: -1 for 0)
+      uint32_t f1, f2, f3;
+      asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(cw.y ^ d1));
+      asm("v_ffbl_b32 %0, %1" : "=v"(f2) : "v"(cw.z ^ d2));
+      asm("v_ffbl_b32 %0, %1" : "=v"(f3) : "v"(cw.w ^ d3));
+      const uint32_t more = min(min(min(f1, f2 | 32u), f3 | 64u) >> 3, 12u); // 0..11, 12: all 12 bytes equal
+      const uint32_t code = (usable && cw.x == word) ? (more < 12u ? 1u : 3u) : 0u;
+      about = (back + 1u) | (more << 26) | (code << 30);
+    }
+    const uint64_t matches = wave_ballot(about >= (1u << 30));
+    uint32_t start = 0; // lane at which the next sequence's window starts
+    uint64_t stale = 0; // lanes whose table slot the trip's sequences have written: what they looked up is no longer there
+    // the next sequence: its match lane, the lanes in the slots of its literal
+    // lanes, and what the match lane says -- 0 if it is not one this path takes
+    int f;
+    uint64_t touched;
+    auto pick = [&]() -> uint32_t {
+      f = first_set_or_minus_one(matches & (~0ull << start)); // (start <= 23 + 15)
+      const uint32_t lit = (uint32_t)f - start; // (no match: huge)
+      if (lit >= 15u)
+        return 0u;
+      const uint32_t a = read_lane(about, f);
+      const uint64_t range = (1ull << f) - (1ull << start); // the literal lanes
+      uint64_t clash = stale & (range | (1ull << f));
+      touched = 0;
+      for (uint32_t u = start; u < (uint32_t)f; ++u) {
+        const uint64_t same_slot = wave_ballot(hpos == read_lane(hpos, (int)u));
+        clash |= same_slot & range & (~1ull << u);
+        touched |= same_slot;
+      }
+      return (clash == 0 && (a >> 30) == 1u) ? a : 0u;
+    };
+    uint32_t a = pick();
+    while (a != 0) {
+      const uint32_t lit = (uint32_t)f - start;
+      const uint32_t more = (a >> 26) & 15u;
+      // token, literals, offset in one store: the literal lanes write their own
+      // byte, the lane of the match the token, the two lanes behind it the offset
+      {
+        const uint32_t rel = (uint32_t)lane - start;
+        const uint32_t k = rel - lit - 1u;
+        const bool is_lit = rel < lit;
+        uint32_t val = is_lit ? word : (a & 0xFFFFu) >> (8u * k);
+        val = rel == lit ? (lit << 4) | more : val;
+        const uint32_t off = rel == lit ? 0u : (is_lit ? rel + 1u : rel);
+        if (rel <= lit + 2u)
+          out[c + off] = (uint8_t)val;
+      }
+      c += lit + 3u;
+      // insert the literal lanes (distinct slots)
+      far_store_masked(table, hpos, pos & 0xFFFFu, (1ull << f) - (1ull << start), lane);
+      stale |= touched;
+      start = (uint32_t)f + 4u + more;
+      a = pick();
+    }
+    if (start == 0) {
+      armed = matches != 0;
+      break;
+    }
+    const uint32_t moved = start;
+    wnd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + moved) & 63u) * 4u), (int)next);
+    d += moved;
+    token_start = d;
+    cold = 0;
+    next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word));
+    if (__builtin_expect(moved > kFarSpanReach, 0)) {
+      // (a real branch: as a select it would make every trip wait for the load)
+      asm volatile("" ::: "memory");
+      wnd = next;
+    }
+  }
+  return armed;
+}
+
 template <int S, bool WIDE>
 __device__ __forceinline__ void compress_wave_far(
     const uint8_t* const* __restrict__ in_ptrs,
@@ -1556,8 +1678,12 @@ __device__ __forceinline__ void compress_wave_far(
       while (d < L) {
         // ---- the common windows of data that compresses (far_straight, the
         // form of this kernel)
-        if (straight && token_start == d)
-          straight = far_straight<S, WIDE>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next, 0);
+        if (straight && token_start == d) {
+          if (S == 1 && !WIDE)
+            straight = far_straight_bytes(in, out, table, hmask, L, last_word, lane, d, c, token_start, cold, next);
+          else
+            straight = far_straight<S, WIDE>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next, 0);
+        }
         if (d + LVM >= L) {
           c = write_sequence(out, c, in + (size_t)token_start * S, len - token_start * S, 0, 0, lane);
           break;

@@ -1517,7 +1517,10 @@ __device__ __forceinline__ bool far_straight(
 // written per sequence.  A window that is anything else is left to the caller.  Returns false if the window it
 // stopped at had no table match among those lanes at all.
 // ---------------------------------------------------------------------------
-constexpr int kFarSpan = 24;
+#ifndef HC_FAR_SPAN
+#define HC_FAR_SPAN 24 // (measurement builds; 16: harness 51 / text 38.5 GB/s, 24: 59 / 36.7, 32: 60.5 / 35.3)
+#endif
+constexpr int kFarSpan = HC_FAR_SPAN;
 constexpr uint32_t kFarSpanReach = 64 - (kFarSpan + 12); // bytes the window's words can move down by
 
 __device__ __forceinline__ int first_set_or_minus_one(uint64_t m) // (s_ff1_i32_b64 as it is)

@@ -202,3 +202,61 @@ def sparse_repeats(seed: int, n: int, every: int, length: int) -> bytes:
             a[pos + k] = a[src + k]
         pos += length
     return a.tobytes()
+
+
+def periodic_bytes(seed: int, n: int, period: int, mutate_every: int) -> bytes:
+    """A random pattern of `period` bytes repeated, one byte changed about every `mutate_every`
+    bytes: matches at the distance of the period (shorter than a window for small periods),
+    literal runs of one byte, lanes of a window that share hash slots."""
+    r = splitmix64(seed, period + 2 * (n // max(mutate_every, 1) + 2))
+    pat = (r[:period] & np.uint64(0xFF)).astype(np.uint8)
+    out = np.tile(pat, n // period + 1)[:n].copy()
+    at = 0
+    for k in range(n // max(mutate_every, 1)):
+        at += 1 + int(r[period + 2 * k] % np.uint64(2 * mutate_every))
+        if at >= n:
+            break
+        out[at] = np.uint8(int(r[period + 2 * k + 1]) & 0xFF)
+    return out.tobytes()
+
+
+def small_alphabet_bytes(seed: int, n: int, symbols: int) -> bytes:
+    """Random bytes out of `symbols` values: short matches everywhere, equal words inside a window."""
+    return ((splitmix64(seed, n) % np.uint64(symbols)).astype(np.uint8) + np.uint8(0x41)).tobytes()
+
+
+def vocabulary_text(seed: int, n: int, words: int, longest: int) -> bytes:
+    """Random words out of a vocabulary of `words` (3..longest letters), one separator byte:
+    sequences of a few literals and a short match, candidates near and far."""
+    r = splitmix64(seed, words * (longest + 1) + n // 3 + 8)
+    vocab = []
+    k = 0
+    for _ in range(words):
+        ln = 3 + int(r[k] % np.uint64(longest - 2)); k += 1
+        vocab.append(bytes(0x61 + int(r[k + j] % np.uint64(26)) for j in range(ln)))
+        k += ln
+    parts, total = [], 0
+    while total < n:
+        w = vocab[int(r[k % len(r)] % np.uint64(words))]; k += 1
+        parts.append(w + b" ")
+        total += len(w) + 1
+    return b"".join(parts)[:n]
+
+
+def trip_corner_chunks():
+    """Chunks for the encoders' several-elements-per-trip paths (LZ4 far, Snappy): 64 of them."""
+    out = []
+    for i, p in enumerate((1, 2, 3, 4, 5, 7, 8, 11, 12, 16, 19, 24, 31, 40)):
+        out.append(periodic_bytes(900 + i, 65536 - 13 * i, p, 37 + 11 * i))
+        out.append(periodic_bytes(950 + i, 65536 - 5 * i, p, 9 + i))
+    for i, s in enumerate((2, 3, 4, 5, 8, 16)):
+        out.append(small_alphabet_bytes(1000 + i, 65536 - 31 * i, s))
+        out.append(small_alphabet_bytes(1050 + i, 30000 + 977 * i, s))
+    for i, (w, l) in enumerate(((4, 5), (16, 6), (64, 8), (256, 9), (1024, 12), (4096, 7))):
+        out.append(vocabulary_text(1100 + i, 65536 - 3 * i, w, l))
+        out.append(vocabulary_text(1150 + i, 65536 - 101 * i, w, l))
+    for i in range(6):
+        out.append(text_like(1200 + i, 65536 - i))
+        out.append(tpch_lineitem_text(1250 + i, 65536 - 7 * i))
+    assert len(out) == 64
+    return out

@@ -125,6 +125,36 @@ def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, tname
     assert dec.to_host_chunks() == chunks
 
 
+def test_several_sequences_per_trip_corner_cases(hc, oracle, reflib, cuda):
+    """The far shape's byte path takes several sequences off one trip to memory
+    (far_straight_bytes): periodic data with periods shorter than its span,
+    tiny alphabets (lanes of one window in one table slot, matches that overlap
+    their source), vocabulary text with near and far candidates, real text.  64
+    crafted chunks x 24 (the batch must be larger than what the LDS shape holds
+    for the sampler to choose "far"), every chunk against the oracle and the
+    reference build, then the round trip."""
+    import torch
+    base = datagen.trip_corner_chunks()
+    chunks = base * 24
+    want = [oracle.lz4_compress(c, 1, 65536) for c in base]
+    src = hc.batch.from_host_chunks(chunks, "cuda:0")
+    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(0))
+    mine = codec.compress(src, 65536)
+    torch.cuda.synchronize()
+    got = mine.to_host_chunks()
+    for i in range(len(chunks)):
+        assert got[i] == want[i % len(base)], f"chunk {i}: kernel != oracle"
+    if reflib is not None:
+        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(0), lib=reflib).compress(src, 65536)
+        torch.cuda.synchronize()
+        refgot = ref.to_host_chunks()
+        for i in range(len(base)):
+            assert refgot[i] == want[i], f"chunk {i}: oracle != reference"
+    dec, actual, statuses = codec.decompress(mine, 65536)
+    assert statuses.cpu().tolist() == [0] * len(chunks)
+    assert dec.to_host_chunks() == chunks
+
+
 def test_small_tables_many_waves_per_group(hc, oracle, cuda):
     """max_chunk below 16 KiB: smaller hash tables, up to 16 waves (= chunks
     in flight) per workgroup, batch sizes that do not fill the last group."""

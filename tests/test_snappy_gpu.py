@@ -52,6 +52,33 @@ def test_compress_bit_exact_and_roundtrip(hc, oracle, reflib, cuda):
         assert rdec.to_host_chunks() == chunks
 
 
+def test_several_elements_per_trip_corner_cases(hc, oracle, reflib, cuda):
+    """The encoder's straight path takes several elements off one trip to memory:
+    periodic data with periods shorter than its span, tiny alphabets (lanes of one
+    window with one hash, copies that overlap their source), vocabulary text, real
+    text -- every chunk against the oracle and the reference build, then the round
+    trip."""
+    import torch
+    chunks = datagen.trip_corner_chunks()
+    src = hc.batch.from_host_chunks(chunks, "cuda:0")
+    codec = hc.batch.Codec("Snappy")
+    mine = codec.compress(src)
+    torch.cuda.synchronize()
+    got = mine.to_host_chunks()
+    want = [oracle.snappy_compress(c) for c in chunks]
+    for i in range(len(chunks)):
+        assert got[i] == want[i], f"chunk {i}: kernel != oracle"
+    if reflib is not None:
+        r = hc.batch.Codec("Snappy", lib=reflib).compress(src)
+        torch.cuda.synchronize()
+        refgot = r.to_host_chunks()
+        for i in range(len(chunks)):
+            assert refgot[i] == want[i], f"chunk {i}: oracle != reference build"
+    dec, actual, statuses = codec.decompress(mine, 65536)
+    assert statuses.cpu().tolist() == [0] * len(chunks)
+    assert dec.to_host_chunks() == chunks
+
+
 def test_reference_harness_batches(hc, oracle, reflib, cuda):
     import torch
     for bi, chunks in enumerate(datagen.harness_batches()):

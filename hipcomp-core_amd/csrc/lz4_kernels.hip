@@ -80,6 +80,9 @@ __device__ __forceinline__ uint32_t write_lsic(gptr out, uint32_t number, int la
 {
   const uint32_t num = number / 255u + 1u;
   const uint8_t last = (uint8_t)(number % 255u);
+  // (one trip nearly always; unrolled eight times the compiler keeps eight
+  // lane offsets in registers for the whole kernel)
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (uint32_t i = (uint32_t)lane; i < num; i += kWave)
     out[i] = (i + 1 < num) ? (uint8_t)0xFF : last;
   return num;
@@ -1504,7 +1507,7 @@ __device__ __forceinline__ bool far_straight(
 }
 
 // ---------------------------------------------------------------------------
-// The lean form for byte elements, several sequences per trip to memory: the
+// The lean form, several sequences per trip to memory: the
 // first kFarSpan lanes look their table slots up and fetch 16 bytes at their
 // candidates -- they hold the match length of a match shorter than 16 bytes as
 // well -- and the sequences are then taken off one after the other in registers
@@ -1521,7 +1524,6 @@ __device__ __forceinline__ bool far_straight(
 #define HC_FAR_SPAN 24 // (measurement builds; 16: harness 51 / text 38.5 GB/s, 24: 59 / 36.7, 32: 60.5 / 35.3)
 #endif
 constexpr int kFarSpan = HC_FAR_SPAN;
-constexpr uint32_t kFarSpanReach = 64 - (kFarSpan + 12); // bytes the window's words can move down by
 
 __device__ __forceinline__ int first_set_or_minus_one(uint64_t m) // (s_ff1_i32_b64 as it is)
 {
@@ -1530,11 +1532,16 @@ __device__ __forceinline__ int first_set_or_minus_one(uint64_t m) // (s_ff1_i32_
   return r;
 }
 
-__device__ __forceinline__ bool far_straight_bytes(
+template <int S>
+__device__ __forceinline__ bool far_straight_several(
     cgptr __restrict__ in, gptr __restrict__ out, HC_GLOBAL uint16_t* const table,
     const uint32_t hmask, const uint32_t L, const uint32_t last_word, const int lane, uint32_t& d, uint32_t& c,
     uint32_t& token_start, int& cold, uint32_t& next)
 {
+  // lanes (= elements) the window's words can move down by: the path looks at
+  // the words of lanes 0 .. kFarSpan - 1 + 12 / S
+  constexpr uint32_t kReach = 64 - (kFarSpan + 12 / S);
+  constexpr uint32_t kMostLiterals = 14 / S; // < 15 literal bytes: no length bytes
   uint32_t wnd = next;
   bool armed = true;
   while (d + kFarFastMargin <= L) {
@@ -1542,18 +1549,18 @@ __device__ __forceinline__ bool far_straight_bytes(
     const uint32_t hpos = hash_sum(word) & hmask;
     const uint32_t pos = d + (uint32_t)lane;
     // the words 4, 8 and 12 bytes on
-    const uint32_t d1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 4u) & 63u) * 4, (int)word);
-    const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 8u) & 63u) * 4, (int)word);
-    const uint32_t d3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 12u) & 63u) * 4, (int)word);
+    const uint32_t d1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 4u / S) & 63u) * 4, (int)word);
+    const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 8u / S) & 63u) * 4, (int)word);
+    const uint32_t d3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane + 12u / S) & 63u) * 4, (int)word);
     // what a lane says about its table match, in one word: bit 30 set: there is
-    // one, bit 31: of 16 bytes or more, 26-29 match length - 4, 0-15 the offset
+    // one, bit 31: of 16 bytes or more, 26-29 matching bytes - 4, 0-15 the offset in bytes
     uint32_t about = 0;
     if (lane < kFarSpan) {
       const uint32_t h_old = table[hpos];
       const uint32_t back = (pos - 1u - h_old) & 0xFFFFu; // (see window_candidate)
       const uint32_t cand = pos - 1u - back;
-      const bool usable = (h_old != kNullOffset) & (back < 65535u);
-      const u32x4 cw = load_u128_any(in + (usable ? cand : 0u));
+      const bool usable = (h_old != kNullOffset) & (back < 65535u / S);
+      const u32x4 cw = load_u128_any(in + (size_t)(usable ? cand : 0u) * S);
       // first differing byte among bytes 4..15 of the match (v_ffbl_b32: -1 for 0)
       uint32_t f1, f2, f3;
       asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(cw.y ^ d1));
@@ -1561,7 +1568,7 @@ __device__ __forceinline__ bool far_straight_bytes(
       asm("v_ffbl_b32 %0, %1" : "=v"(f3) : "v"(cw.w ^ d3));
       const uint32_t more = min(min(min(f1, f2 | 32u), f3 | 64u) >> 3, 12u); // 0..11, 12: all 12 bytes equal
       const uint32_t code = (usable && cw.x == word) ? (more < 12u ? 1u : 3u) : 0u;
-      about = (back + 1u) | (more << 26) | (code << 30);
+      about = (((back + 1u) * S) & 0xFFFFu) | (more << 26) | (code << 30);
     }
     const uint64_t matches = wave_ballot(about >= (1u << 30));
     uint32_t start = 0; // lane at which the next sequence's window starts
@@ -1571,9 +1578,9 @@ __device__ __forceinline__ bool far_straight_bytes(
     int f;
     uint64_t touched;
     auto pick = [&]() -> uint32_t {
-      f = first_set_or_minus_one(matches & (~0ull << start)); // (start <= 23 + 15)
+      f = first_set_or_minus_one(matches & (~0ull << start)); // (start <= kFarSpan - 1 + 15)
       const uint32_t lit = (uint32_t)f - start; // (no match: huge)
-      if (lit >= 15u)
+      if (lit > kMostLiterals)
         return 0u;
       const uint32_t a = read_lane(about, f);
       const uint64_t range = (1ull << f) - (1ull << start); // the literal lanes
@@ -1589,24 +1596,37 @@ __device__ __forceinline__ bool far_straight_bytes(
     uint32_t a = pick();
     while (a != 0) {
       const uint32_t lit = (uint32_t)f - start;
-      const uint32_t more = (a >> 26) & 15u;
-      // token, literals, offset in one store: the literal lanes write their own
-      // byte, the lane of the match the token, the two lanes behind it the offset
-      {
-        const uint32_t rel = (uint32_t)lane - start;
+      const uint32_t ml = (4u + ((a >> 26) & 15u)) / S; // elements
+      const uint32_t rel = (uint32_t)lane - start;
+      if (S == 1) {
+        // token, literals, offset in one store: the literal lanes write their own
+        // byte, the lane of the match the token, the two lanes behind it the offset
         const uint32_t k = rel - lit - 1u;
         const bool is_lit = rel < lit;
         uint32_t val = is_lit ? word : (a & 0xFFFFu) >> (8u * k);
-        val = rel == lit ? (lit << 4) | more : val;
+        val = rel == lit ? (lit << 4) | (ml - 4u) : val;
         const uint32_t off = rel == lit ? 0u : (is_lit ? rel + 1u : rel);
         if (rel <= lit + 2u)
           out[c + off] = (uint8_t)val;
+      } else {
+        // the literal lanes write their own element; the lane of the match the
+        // token, the two lanes behind it the offset
+        const uint32_t k = rel - lit - 1u;
+        if (rel < lit) {
+          if (S == 2)
+            *reinterpret_cast<HC_GLOBAL uint16_t __attribute__((aligned(1)))*>(out + c + 1u + rel * S) = (uint16_t)word;
+          else
+            *reinterpret_cast<HC_GLOBAL u32_unaligned*>(out + c + 1u + rel * S) = word;
+        }
+        const uint32_t val = rel == lit ? ((lit * S) << 4) | (ml * S - 4u) : (a & 0xFFFFu) >> (8u * k);
+        if (rel >= lit && rel <= lit + 2u)
+          out[c + (rel == lit ? 0u : lit * S + k + 1u)] = (uint8_t)val;
       }
-      c += lit + 3u;
+      c += lit * S + 3u;
       // insert the literal lanes (distinct slots)
       far_store_masked(table, hpos, pos & 0xFFFFu, (1ull << f) - (1ull << start), lane);
       stale |= touched;
-      start = (uint32_t)f + 4u + more;
+      start = (uint32_t)f + ml;
       a = pick();
     }
     if (start == 0) {
@@ -1618,8 +1638,8 @@ __device__ __forceinline__ bool far_straight_bytes(
     d += moved;
     token_start = d;
     cold = 0;
-    next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word));
-    if (__builtin_expect(moved > kFarSpanReach, 0)) {
+    next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+    if (__builtin_expect(moved > kReach, 0)) {
       // (a real branch: as a select it would make every trip wait for the load)
       asm volatile("" ::: "memory");
       wnd = next;
@@ -1666,7 +1686,11 @@ __device__ __forceinline__ void compress_wave_far(
         u32x4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         HC_GLOBAL u32x4* p = reinterpret_cast<HC_GLOBAL u32x4*>(table);
         const uint32_t nvec = ((ht_size * 2 + 15) & ~15u) >> 4;
-        for (uint32_t i = (uint32_t)lane; i < nvec; i += kWave)
+        // (the lane's first address is made here, per chunk: as a loop invariant of
+        // the whole kernel it costs two registers that the lean forms do not have)
+        uint32_t i0 = (uint32_t)lane;
+        asm volatile("" : "+v"(i0));
+        for (uint32_t i = i0; i < nvec; i += kWave)
           p[i] = ones;
       }
       uint32_t d = 0, c = 0;
@@ -1682,8 +1706,8 @@ __device__ __forceinline__ void compress_wave_far(
         // ---- the common windows of data that compresses (far_straight, the
         // form of this kernel)
         if (straight && token_start == d) {
-          if (S == 1 && !WIDE)
-            straight = far_straight_bytes(in, out, table, hmask, L, last_word, lane, d, c, token_start, cold, next);
+          if (!WIDE)
+            straight = far_straight_several<S>(in, out, table, hmask, L, last_word, lane, d, c, token_start, cold, next);
           else
             straight = far_straight<S, WIDE>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next, 0);
         }

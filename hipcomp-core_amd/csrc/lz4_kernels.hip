@@ -1591,10 +1591,10 @@ __device__ __forceinline__ bool far_straight_several(
         clash |= same_slot & range & (~1ull << u);
         touched |= same_slot;
       }
-      return (clash == 0 && (a >> 30) == 1u) ? a : 0u;
+      return clash == 0 ? a : 0u;
     };
     uint32_t a = pick();
-    while (a != 0) {
+    while ((a >> 30) == 1u) {
       const uint32_t lit = (uint32_t)f - start;
       const uint32_t ml = (4u + ((a >> 26) & 15u)) / S; // elements
       const uint32_t rel = (uint32_t)lane - start;
@@ -1628,6 +1628,16 @@ __device__ __forceinline__ bool far_straight_several(
       stale |= touched;
       start = (uint32_t)f + ml;
       a = pick();
+    }
+    if ((a >> 30) == 3u) {
+      // a match of 16 bytes or more ends the trip: its length from memory, the
+      // sequence by the general writer
+      const uint32_t lit = (uint32_t)f - start;
+      const uint32_t mpos = d + (uint32_t)f, offset_bytes = a & 0xFFFFu;
+      const uint32_t ml = match_length<S>(in, mpos - offset_bytes / S, mpos, L - mpos - (5 + S - 1) / S, lane);
+      c = write_sequence(out, c, in + (size_t)(d + start) * S, lit * S, ml * S, offset_bytes, lane);
+      far_store_masked(table, hpos, pos & 0xFFFFu, (1ull << f) - (1ull << start), lane);
+      start = (uint32_t)f + ml;
     }
     if (start == 0) {
       armed = matches != 0;

@@ -127,7 +127,7 @@ def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, tname
 
 def test_several_sequences_per_trip_corner_cases(hc, oracle, reflib, cuda):
     """The far shape's byte path takes several sequences off one trip to memory
-    (far_straight_bytes): periodic data with periods shorter than its span,
+    (far_straight_several): periodic data with periods shorter than its span,
     tiny alphabets (lanes of one window in one table slot, matches that overlap
     their source), vocabulary text with near and far candidates, real text.  64
     crafted chunks x 24 (the batch must be larger than what the LDS shape holds

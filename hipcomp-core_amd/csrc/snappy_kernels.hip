@@ -538,6 +538,41 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
           const uint32_t e = tag_lut[t & 0xFFu];
           const uint32_t blen = e & 0xFFu, need = (e >> 8) & 0xFFu;
           const bool lit = (e & (1u << 16)) != 0u;
+          // ---- a literal of up to 32 bytes and the copy behind it as one step
+          // (what text is made of): lanes below the literal's length carry its
+          // bytes, the lanes behind them the copy's, whose source may be those
+          // very literal bytes (then they come from the stream window too, not
+          // from out[]).  Anything else about the pair leaves it to the code
+          // below, one element at a time.
+          if (wave_ballot(lit) != 0) {
+            const uint32_t t2 = sw.bytes_at(vcur - sw.base + need); // (need <= 61: inside the window)
+            const uint32_t e2 = tag_lut[t2 & 0xFFu];
+            const uint32_t blen2 = e2 & 0xFFu, need2 = (e2 >> 8) & 0xFFu;
+            const uint32_t off16b = (t2 >> 8) & 0xFFFFu;
+            const uint32_t offset2 = (e2 & (1u << 17)) ? ((t2 & 0xe0u) << 3) | (off16b & 0xFFu) : off16b;
+            const uint32_t n = blen + blen2;
+            // both tags for this path, the second a copy; <= 64 bytes that fit what
+            // is left of the output and of the stream; 0 < offset <= dst + literal
+            const uint32_t bad2 = e | e2 | ((e2 & (1u << 16)) ? ~0u : 0u) | (32u - blen) | ((uint32_t)kWave - n) | (vleft - n)
+                                  | (avail - need - need2) | (offset2 - 1u) | (vdst + blen - offset2);
+            if (wave_ballot((int32_t)bad2 < 0) == 0) {
+              uint32_t k = i - blen; // copy byte index (lanes behind the literal)
+              if (wave_ballot(offset2 < blen2) != 0)
+                k = small_mod(k & 63u, offset2);
+              const int32_t s = (int32_t)(blen + k - offset2); // its source relative to dst; >= 0: a byte of the literal
+              const bool from_window = i < blen || s >= 0;
+              const uint32_t widx = vcur - sw.base + 1u + (i < blen ? i : (uint32_t)max(s, 0));
+              const uint32_t wword = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(widx & ~3u), (int)sw.words);
+              if (i < n) {
+                const uint32_t ob = static_cast<cgptr>(out)[vdst + (from_window ? i : (uint32_t)s)];
+                out[vdst + i] = (uint8_t)(from_window ? wword >> ((widx & 3u) * 8u) : ob);
+              }
+              vcur += need + need2;
+              vdst += n;
+              vleft -= n;
+              continue;
+            }
+          }
           const uint32_t off16 = (t >> 8) & 0xFFFFu;
           const uint32_t offset = (e & (1u << 17)) ? ((t & 0xe0u) << 3) | (off16 & 0xFFu) : off16;
           // tag for this path; fits what is left of the output and of the

@@ -111,12 +111,14 @@ __device__ __forceinline__ uint32_t wave_rle(
   for (uint32_t base = 0; base < n; base += kWave) {
     const uint32_t i = base + (uint32_t)lane;
     const bool active = i < n;
-    const UT v = active ? in[i] : (UT)0;
-    const UT nx = (i + 1 < n) ? in[i + 1] : (UT)0;
+    // (read whether or not the lane has an element: the buffer holds a multiple
+    // of 64 elements and one more, and what lies behind n is not used)
+    const UT v = in[i];
+    const UT nx = in[i + 1];
     const bool is_end = active && (i + 1 == n || nx != v);
     const uint64_t mask = wave_ballot(is_end);
     const uint64_t below = mask & below_me;
-    const uint32_t rank = m + (uint32_t)__builtin_popcountll(below);
+    const uint32_t rank = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     const uint32_t pe = below ? base + 64u - (uint32_t)__builtin_clzll(below) : prev_end;
     if (is_end) {
       vals[rank] = v;
@@ -203,6 +205,33 @@ __device__ __forceinline__ uint32_t wave_write_array(
     }
   }
   HC_GLOBAL uint32_t* data = dst + HDR / 4;
+  if (ES <= 4) {
+    // LSB-first packing of (x - FOR) in bw bits (reference :523-552), a lane per
+    // output word: the first element of the word from a float reciprocal (exact
+    // to within one for these sizes, then corrected), each element moved into
+    // place by one 64-bit shift
+    const float rbw = __builtin_amdgcn_rcpf((float)bw); // (words > 0: bw >= 1)
+    for (uint32_t w = (uint32_t)lane; w < words; w += kWave) {
+      const uint32_t b0 = w * 32;
+      uint32_t i = (uint32_t)((float)b0 * rbw);
+      int32_t sh = (int32_t)(i * bw) - (int32_t)b0; // bit of the word at which element i starts: (-bw, 0] for the first one
+      if (sh > 0) {
+        --i;
+        sh -= (int32_t)bw;
+      }
+      if (sh <= -(int32_t)bw) {
+        ++i;
+        sh += (int32_t)bw;
+      }
+      uint32_t acc = 0;
+      for (; sh < 32 && i < n; ++i, sh += (int32_t)bw) {
+        const uint32_t x = (uint32_t)(ET)(v[i] - fr);
+        acc |= (uint32_t)(((uint64_t)x << (uint32_t)(sh + 32)) >> 32);
+      }
+      data[w] = acc;
+    }
+    return ob;
+  }
   for (uint32_t w = (uint32_t)lane; w < words; w += kWave) {
     // LSB-first packing of (x - FOR) in bw bits (reference :523-552)
     const uint32_t b0 = w * 32;

@@ -1586,9 +1586,11 @@ __device__ __forceinline__ bool far_straight_several(
       const uint64_t range = (1ull << f) - (1ull << start); // the literal lanes
       uint64_t clash = stale & (range | (1ull << f));
       touched = 0;
+      // (a literal lane in the slot of the match lane as well: the match lane may
+      // then be the duplicate of a lower lane, which the general code settles)
       for (uint32_t u = start; u < (uint32_t)f; ++u) {
         const uint64_t same_slot = wave_ballot(hpos == read_lane(hpos, (int)u));
-        clash |= same_slot & range & (~1ull << u);
+        clash |= same_slot & (range | (1ull << f)) & (~1ull << u);
         touched |= same_slot;
       }
       return clash == 0 ? a : 0u;

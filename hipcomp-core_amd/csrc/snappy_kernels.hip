@@ -63,10 +63,10 @@ constexpr uint32_t kStraightMargin = 64 + 8 + 64 + 8;
 // words of lanes 0..kSpan+11, which come from the window before if the elements
 // moved on by no more than kStraightReach bytes
 #ifndef HC_SNAPPY_SPAN
-#define HC_SNAPPY_SPAN 24 // (measurement builds: 16..40)
+#define HC_SNAPPY_SPAN 40 // (measurement builds: 16..52)
 #endif
 constexpr int kSpan = HC_SNAPPY_SPAN;
-constexpr uint32_t kStraightReach = 64 - (kSpan + 12);
+constexpr uint32_t kStraightReach = 64; // (two registers of words: all 64 lanes of the next window are there)
 
 __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     const uint8_t* const* __restrict__ in_ptrs,
@@ -127,6 +127,9 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
   // down by the bytes the element took (ds_bpermute; the lanes that path looks
   // at are all there), so that the load is off the chain from element to element.
   uint32_t next = len >= 4 ? load_u32_any(src + min((uint32_t)lane, last_word)) : 0;
+  // (and the 64 words behind them: the elements of one trip may move on by more
+  // than the lanes the straight path looks at leave of a single window)
+  uint32_t next_hi = len >= 4 ? load_u32_any(src + min(64u + (uint32_t)lane, last_word)) : 0;
   uint32_t wnd = next;
   while (pos < len) {
     const uint32_t pos0 = pos;
@@ -253,9 +256,12 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
       if (start != 0) {
         const uint32_t moved = start;
         pos = pos0 + moved;
-        const uint32_t moved_words = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + moved) & 63u) * 4u), (int)next);
+        const int from4 = (int)((((uint32_t)lane + moved) & 63u) * 4u);
+        const uint32_t moved_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(from4, (int)next);
+        const uint32_t moved_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from4, (int)next_hi);
         next = load_u32_any(src + min(pos + (uint32_t)lane, last_word));
-        wnd = moved_words;
+        next_hi = load_u32_any(src + min(pos + 64u + (uint32_t)lane, last_word));
+        wnd = (uint32_t)lane + moved < 64u ? moved_lo : moved_hi;
         if (__builtin_expect(moved > kStraightReach, 0)) {
           // (a real branch: as a select it would make every trip wait for the load)
           asm volatile("" ::: "memory");
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     }
     pos = pos0 + lit + copy_len;
     next = load_u32_any(src + min(pos + (uint32_t)lane, last_word));
+    next_hi = load_u32_any(src + min(pos + 64u + (uint32_t)lane, last_word));
     wnd = next;
   }
   if (lane == 0)

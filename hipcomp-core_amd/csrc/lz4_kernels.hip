@@ -1390,6 +1390,12 @@ __device__ __forceinline__ bool far_straight(
     uint32_t& token_start, int& cold, uint32_t& next, const int only_one)
 {
   uint32_t wnd = next;
+  // (wide: the 64 words behind the window's as well -- all 64 lanes of the next
+  // window then hold its words whatever the sequence moved by, and the length of
+  // a match against a lower lane can be read off the window)
+  uint32_t next_hi = 0;
+  if (WIDE)
+    next_hi = load_u32_any(in + (size_t)min(d + 64u + (uint32_t)lane, last_word) * S);
   bool armed = true;
   while (d + kFarFastMargin <= L) {
     const uint32_t word = wnd;
@@ -1405,6 +1411,7 @@ __device__ __forceinline__ bool far_straight(
     const uint64_t tmask = wave_ballot(usable & (cand_word == word));
     int f;
     uint32_t mloc;
+    uint32_t below_by = 0; // wide: the match is the lane this many lanes below (0: a table match)
     if (!WIDE) {
       if (tmask == 0) {
         armed = false;
@@ -1434,7 +1441,9 @@ __device__ __forceinline__ bool far_straight(
       }
       if (dups) {
         f = __builtin_ctzll(dups);
-        mloc = d + (uint32_t)__builtin_ctzll(wave_ballot(word == read_lane(word, f))); // lowest lane holding the word
+        const uint32_t lowest = (uint32_t)__builtin_ctzll(wave_ballot(word == read_lane(word, f))); // lowest lane holding the word
+        mloc = d + lowest;
+        below_by = (uint32_t)f - lowest;
       } else if (tmask) {
         f = k;
         mloc = read_lane(cand, k);
@@ -1446,20 +1455,36 @@ __device__ __forceinline__ bool far_straight(
     const uint32_t mpos = d + (uint32_t)f;
     // match length: the first 32 bytes (8 lanes, one line each side); the wide
     // form goes on with the general search
-    uint32_t x = 0;
-    if (lane < 8)
-      x = load_u32_any(in + (size_t)mloc * S + 4u * (uint32_t)lane)
-          ^ load_u32_any(in + (size_t)mpos * S + 4u * (uint32_t)lane);
-    const uint32_t diff_at = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
-    const uint64_t stop = wave_ballot(diff_at < 4u);
-    uint32_t ml;
-    if (stop) {
-      const int sl = __builtin_ctzll(stop);
-      ml = (4u * (uint32_t)sl + read_lane(diff_at, sl)) / S;
-    } else if (WIDE) {
-      ml = match_length<S>(in, mloc, mpos, L - mpos - (5 + S - 1) / S, lane);
-    } else {
-      break;
+    uint32_t ml = 0;
+    bool have_length = false;
+    if (WIDE && below_by != 0) {
+      // against a lower lane of the window: the words are all here -- the first
+      // lane from f on whose word differs from the one below_by lanes below, and
+      // the equal low bytes of that word
+      const uint32_t theirs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane - below_by) & 63u) * 4u), (int)word);
+      const uint32_t differ = word ^ theirs;
+      const uint64_t stops = wave_ballot(differ != 0) & ~lanes_below<64>(f);
+      if (stops) {
+        const int q = __builtin_ctzll(stops);
+        ml = (((uint32_t)(q - f)) * S + ((uint32_t)__builtin_ctz(read_lane(differ, q)) >> 3)) / S;
+        have_length = true;
+      }
+    }
+    if (!have_length) {
+      uint32_t x = 0;
+      if (lane < 8)
+        x = load_u32_any(in + (size_t)mloc * S + 4u * (uint32_t)lane)
+            ^ load_u32_any(in + (size_t)mpos * S + 4u * (uint32_t)lane);
+      const uint32_t diff_at = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+      const uint64_t stop = wave_ballot(diff_at < 4u);
+      if (stop) {
+        const int sl = __builtin_ctzll(stop);
+        ml = (4u * (uint32_t)sl + read_lane(diff_at, sl)) / S;
+      } else if (WIDE) {
+        ml = match_length<S>(in, mloc, mpos, L - mpos - (5 + S - 1) / S, lane);
+      } else {
+        break;
+      }
     }
     const uint32_t lit_bytes = (uint32_t)f * S, match_bytes = ml * S;
     if (lit_bytes >= 15u || match_bytes >= (WIDE ? 19u + 255u : 19u))
@@ -1491,13 +1516,19 @@ __device__ __forceinline__ bool far_straight(
     // memory, long there) if the sequence left them inside it
     const uint32_t moved = (uint32_t)f + ml;
     wnd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + moved) & 63u) * 4u), (int)next);
+    if (WIDE) {
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + moved) & 63u) * 4u), (int)next_hi);
+      wnd = (uint32_t)lane + moved < 64u ? wnd : hi;
+    }
     d = mpos + ml;
     token_start = d;
     cold = 0;
     next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+    if (WIDE)
+      next_hi = load_u32_any(in + (size_t)min(d + 64u + (uint32_t)lane, last_word) * S);
     if (only_one)
       break;
-    if (WIDE && __builtin_expect(moved > 56u, 0)) {
+    if (WIDE && __builtin_expect(moved > 64u, 0)) {
       // (a real branch: as a select it would make every trip wait for the load)
       asm volatile("" ::: "memory");
       wnd = next;

@@ -1407,7 +1407,11 @@ __device__ __forceinline__ bool far_straight(
     const uint32_t back = (pos - 1u - h_old) & 0xFFFFu; // (see window_candidate)
     const uint32_t cand = pos - 1u - back;
     const bool usable = (h_old != kNullOffset) & (back < 65535u / S);
-    const uint32_t cand_word = load_u32_any(in + (size_t)(usable ? cand : pos) * S);
+    // (no lane with a candidate -- values never seen before, as in runs of new
+    // values: no trip to memory for them)
+    uint32_t cand_word = ~word;
+    if (!WIDE || wave_ballot(usable) != 0)
+      cand_word = load_u32_any(in + (size_t)(usable ? cand : pos) * S);
     const uint64_t tmask = wave_ballot(usable & (cand_word == word));
     int f;
     uint32_t mloc;

@@ -2330,7 +2330,12 @@ hipError_t lz4_launch_compress(
   Lz4CompressShape far = {};
   far.plain = kFarWavesPerGroup;
   far.lds_bytes = kFarWavesPerGroup * kFarScratchSlots * (uint32_t)sizeof(uint16_t);
-  far.groups = (uint32_t)num_cus_of_current_device() * kFarGroupsPerCu;
+  static const uint32_t far_groups_per_cu = [] { // (measurement knob: fewer resident waves)
+    const char* e = std::getenv("HIPCOMP_LZ4_FAR_GROUPS");
+    const int v = e ? std::atoi(e) : 0;
+    return (uint32_t)(v >= 1 && v <= kFarGroupsPerCu ? v : kFarGroupsPerCu);
+  }();
+  far.groups = (uint32_t)num_cus_of_current_device() * far_groups_per_cu;
   if ((size_t)far.groups * kFarWavesPerGroup > far_capacity)
     far.groups = (uint32_t)(far_capacity / kFarWavesPerGroup);
   // it needs the ticket counter, and pays once the batch is more than the mix

@@ -76,7 +76,7 @@ def test_sparse_matches_walk_and_rollback(hc, oracle, reflib, cuda, tname, dtype
     assert dec.to_host_chunks() == chunks
 
 
-@pytest.mark.parametrize("tname,dtype,es", [TYPES[0], TYPES[2]])
+@pytest.mark.parametrize("tname,dtype,es", TYPES)
 def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, tname, dtype, es):
     """A batch of data that compresses, larger than the LDS-table shape holds in
     flight: the sampling kernel calls for the "far" shape (hash tables in the
@@ -125,7 +125,8 @@ def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, tname
     assert dec.to_host_chunks() == chunks
 
 
-def test_several_sequences_per_trip_corner_cases(hc, oracle, reflib, cuda):
+@pytest.mark.parametrize("tname,dtype,es", TYPES)
+def test_several_sequences_per_trip_corner_cases(hc, oracle, reflib, cuda, tname, dtype, es):
     """The far shape's byte path takes several sequences off one trip to memory
     (far_straight_several): periodic data with periods shorter than its span,
     tiny alphabets (lanes of one window in one table slot, matches that overlap
@@ -134,22 +135,22 @@ def test_several_sequences_per_trip_corner_cases(hc, oracle, reflib, cuda):
     for the sampler to choose "far"), every chunk against the oracle and the
     reference build, then the round trip."""
     import torch
-    base = datagen.trip_corner_chunks()
+    base = [c[: len(c) // es * es] for c in datagen.trip_corner_chunks()]
     chunks = base * 24
-    want = [oracle.lz4_compress(c, 1, 65536) for c in base]
+    want = [oracle.lz4_compress(c, es, 65536) for c in base]
     src = hc.batch.from_host_chunks(chunks, "cuda:0")
-    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(0))
+    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
     mine = codec.compress(src, 65536)
     torch.cuda.synchronize()
     got = mine.to_host_chunks()
     for i in range(len(chunks)):
         assert got[i] == want[i % len(base)], f"chunk {i}: kernel != oracle"
     if reflib is not None:
-        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(0), lib=reflib).compress(src, 65536)
+        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=reflib).compress(src, 65536)
         torch.cuda.synchronize()
         refgot = ref.to_host_chunks()
         for i in range(len(base)):
-            assert refgot[i] == want[i], f"chunk {i}: oracle != reference"
+            assert refgot[i] == want[i], f"chunk {i} {tname}: oracle != reference"
     dec, actual, statuses = codec.decompress(mine, 65536)
     assert statuses.cpu().tolist() == [0] * len(chunks)
     assert dec.to_host_chunks() == chunks

@@ -54,6 +54,12 @@ __device__ __forceinline__ int first_set_or_minus_one(uint64_t m)
   return r;
 }
 
+// number of lanes below mine that are set in m
+__device__ __forceinline__ uint32_t lanes_set_below(uint64_t m)
+{
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // lanes of a window whose table candidates the encoder fetches before the others'
 constexpr int kFirstLanes = 8;
 // bytes a window must have ahead of it for the straight path (the window's words
@@ -197,36 +203,66 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         word_of_lane = (two ? tag2 : tag3) | (extra << 26) | (code << 30);
       }
       const uint64_t events = wave_ballot(word_of_lane >= (1u << 30));
-      // The elements, one after the other.  (One loop condition, and the lane
-      // select -1 of "no event" reads lane 63, whose word is 0: the compiler
-      // gives a loop with several exits a guard variable per exit.)
+      // The elements, one after the other: which lanes they start and hit at is
+      // all the loop notes (one loop condition, and the lane select -1 of "no
+      // event" reads lane 63, whose word is 0: the compiler gives a loop with
+      // several exits a guard variable per exit).  A match of 16 bytes or more
+      // ends the trip and is written on its own below.
       uint32_t start = 0;                        // lane at which the next element's window starts
       uint64_t hit_lanes = 0, start_lanes = 0;   // (as bit sets) of the elements taken
       int t = first_set_or_minus_one(events);
       uint32_t about = read_lane(word_of_lane, t & 63);
-      while ((about & (1u << 30)) != 0) {
+      while ((about >> 30) == 1u) {
+        asm("s_bitset1_b64 %0, %1" : "+s"(hit_lanes) : "s"(t));
+        asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
+        start = (uint32_t)t + 4u + ((about >> 26) & 15u);
+        t = first_set_or_minus_one(events & (~0ull << min(start, 63u))); // (bit 63 of events is never set)
+        about = read_lane(word_of_lane, t & 63);
+      }
+      // Their bytes, all at once: [literal tag, literals] copy element per
+      // element, in lane order.  Where a lane's byte goes is a count of the
+      // lanes below it -- literal lanes, literal tags (one per element that has
+      // literals), copy elements (two bytes each, three for some) -- so every
+      // literal lane writes its own byte, the first one of an element its tag in
+      // front of that, the hit lane its copy element.
+      if (hit_lanes != 0) {
+        const uint64_t lits = ((hit_lanes << 1) - start_lanes) & ~hit_lanes; // lanes start..hit-1 of every element
+        const uint64_t firsts = start_lanes & ~hit_lanes;                    // (an element without literals starts at its hit)
+        const uint64_t threes = wave_ballot(((word_of_lane >> 24) & 3u) == 3u) & hit_lanes;
+        const bool is_hit = ((hit_lanes >> lane) & 1ull) != 0, is_lit = ((lits >> lane) & 1ull) != 0;
+        const bool is_first = ((firsts >> lane) & 1ull) != 0, is_three = ((threes >> lane) & 1ull) != 0;
+        const uint32_t at = c + lanes_set_below(lits) + lanes_set_below(firsts) + (is_first ? 1u : 0u)
+                            + 2u * lanes_set_below(hit_lanes) + lanes_set_below(threes);
+        if (is_hit)
+          *reinterpret_cast<HC_GLOBAL uint16_t __attribute__((aligned(1)))*>(dst + at) = (uint16_t)word_of_lane;
+        if (is_three)
+          dst[at + 2u] = (uint8_t)(word_of_lane >> 16);
+        if (is_lit)
+          dst[at] = (uint8_t)data32;
+        if (is_first) // its literals run up to the element's hit lane
+          dst[at - 1u] = (uint8_t)(((uint32_t)__builtin_ctzll((hit_lanes >> lane) | (1ull << 63)) - 1u) << 2);
+        c += (uint32_t)__builtin_popcountll(lits) + (uint32_t)__builtin_popcountll(firsts)
+             + 2u * (uint32_t)__builtin_popcountll(hit_lanes) + (uint32_t)__builtin_popcountll(threes);
+      }
+      if (__builtin_expect(about >= (3u << 30), 0)) {
+        // Match60 (reference :251-269; 60 bytes are there), then the element --
+        // [literal tag, literals] copy element -- in one store: the literal lanes
+        // write their own byte, the lane of the hit the literal tag, the lanes
+        // behind it the copy element
         lit = (uint32_t)t - start;
-        uint32_t xt = (about >> 26) & 15u; // copy length - 4
-        uint32_t copy_tag = about & 0xFFFFFFu, copy_bytes = (about >> 24) & 3u;
-        if (__builtin_expect(about >= (3u << 30), 0)) { // Match60 (reference :251-269; 60 bytes are there)
-          distance = read_lane(dist, t);
-          const uint32_t match_pos = pos0 + (uint32_t)t + 4;
-          bool mis = true;
-          if (lane < 60)
-            mis = src[match_pos + lane] != src[match_pos - distance + lane];
-          xt = (uint32_t)__builtin_ctzll(wave_ballot(mis));
-          copy_tag = (((xt + 3u) << 2) | 0x2u) | (distance << 8);
-          copy_bytes = 3;
-        }
-        // the element -- [literal tag, literals] copy element, <= 1 + 23 + 3 bytes --
-        // in one store: the literal lanes write their own byte, the lane of the hit
-        // the literal tag, the lanes behind it the copy element
+        distance = read_lane(dist, t);
+        const uint32_t match_pos = pos0 + (uint32_t)t + 4;
+        bool mis = true;
+        if (lane < 60)
+          mis = src[match_pos + lane] != src[match_pos - distance + lane];
+        const uint32_t xt = (uint32_t)__builtin_ctzll(wave_ballot(mis));
+        const uint32_t copy_tag = (((xt + 3u) << 2) | 0x2u) | (distance << 8);
         {
           const uint32_t rel = (uint32_t)lane - start;
           const uint32_t k = rel - lit - 1u;
           const bool is_lit = rel < lit;
           const bool is_tag = lit > 0 && rel == lit;
-          const bool is_copy = k < copy_bytes;
+          const bool is_copy = k < 3u;
           uint32_t val = is_lit ? data32 : copy_tag >> (8u * k);
           val = is_tag ? (lit - 1u) << 2 : val;
           uint32_t off = rel + (is_lit ? 1u : (lit > 0 ? 0u : ~0u));
@@ -234,12 +270,10 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
           if (is_lit || is_tag || is_copy)
             dst[c + off] = (uint8_t)val;
         }
-        c += lit + (lit > 0 ? 1u : 0u) + copy_bytes;
+        c += lit + (lit > 0 ? 1u : 0u) + 3u;
         asm("s_bitset1_b64 %0, %1" : "+s"(hit_lanes) : "s"(t));
         asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
         start = (uint32_t)t + 4u + xt;
-        t = first_set_or_minus_one(events & (~0ull << min(start, 63u))); // (bit 63 of events is never set)
-        about = read_lane(word_of_lane, t & 63);
       }
       // lanes start..hit of every element: their hash-map update stays
       const uint64_t stay = (hit_lanes << 1) - start_lanes;

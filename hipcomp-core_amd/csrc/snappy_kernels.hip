@@ -171,6 +171,7 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
       // 26-29 copy length - 4, 24-25 bytes of the copy element, 0-23 those bytes
       uint32_t word_of_lane = 0;
       uint32_t dist = 0;
+      bool shares = false; // a higher lane (of the kSpan) has my hash
       if (lane < kSpan) {
         h_old = hash_map[hash];
         uint32_t toff = (pos0 & ~0xffffu) | h_old;
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         asm("v_ffbl_b32 %0, %1" : "=v"(f2) : "v"(cand.z ^ d2));
         asm("v_ffbl_b32 %0, %1" : "=v"(f3) : "v"(cand.w ^ d3));
         const uint32_t extra = min(min(min(f1, f2 | 32u), f3 | 64u) >> 3, 12u); // 0..11, 12: all 12 bytes equal
-        uint32_t code = (tprobe && cand.x == data32) ? (extra < 12u ? 1u : 3u) : 0u;
-        code = posted != (my & 0xFFFFu) ? 2u : code;
+        const uint32_t code = (tprobe && cand.x == data32) ? (extra < 12u ? 1u : 3u) : 0u;
+        shares = posted != (my & 0xFFFFu);
         // the copy element (reference StoreCopy :118-151)
         const bool two = (int32_t)((extra - 8u) & (dist - 2048u)) < 0; // extra < 8 and dist < 2048
         const uint32_t tag2 = (((dist & 0x700u) >> 3) | (extra << 2) | 0x01u) | ((dist & 0xFFu) << 8) | (2u << 24);
@@ -203,21 +204,42 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         word_of_lane = (two ? tag2 : tag3) | (extra << 26) | (code << 30);
       }
       const uint64_t events = wave_ballot(word_of_lane >= (1u << 30));
+      const uint64_t sharing = wave_ballot(shares);
       // The elements, one after the other: which lanes they start and hit at is
-      // all the loop notes (one loop condition, and the lane select -1 of "no
-      // event" reads lane 63, whose word is 0: the compiler gives a loop with
-      // several exits a guard variable per exit).  A match of 16 bytes or more
-      // ends the trip and is written on its own below.
+      // all the loop notes.  An element is taken if no two of its lanes (start
+      // .. hit) have one hash -- the later one might hit the earlier one -- and
+      // none of them has the hash of a lane an earlier element of the trip has
+      // put into the hash map (what it looked up was read before that); only a
+      // lane that has a higher lane with its hash can be either, and for those
+      // the lanes with that hash are found with a ballot.  A match of 16 bytes
+      // or more ends the trip and is written on its own below.
       uint32_t start = 0;                        // lane at which the next element's window starts
       uint64_t hit_lanes = 0, start_lanes = 0;   // (as bit sets) of the elements taken
-      int t = first_set_or_minus_one(events);
-      uint32_t about = read_lane(word_of_lane, t & 63);
+      uint64_t stale = 0;                        // lanes with the hash of a lane taken so far
+      int t;
+      uint64_t touched;
+      auto pick = [&]() -> uint32_t {
+        t = first_set_or_minus_one(events & (~0ull << min(start, 63u))); // (bit 63 of events is never set)
+        if (t < 0)
+          return 0u;
+        const uint64_t range = (2ull << t) - (1ull << start); // lanes start..t
+        uint64_t clash = stale & range;
+        touched = 0;
+        for (uint64_t todo = sharing & range; todo != 0; todo &= todo - 1) {
+          const int u = __builtin_ctzll(todo);
+          const uint64_t same_hash = wave_ballot(hash == read_lane(hash, u));
+          clash |= same_hash & range & (~1ull << u);
+          touched |= same_hash;
+        }
+        return clash == 0 ? read_lane(word_of_lane, t) : 0u;
+      };
+      uint32_t about = pick();
       while ((about >> 30) == 1u) {
         asm("s_bitset1_b64 %0, %1" : "+s"(hit_lanes) : "s"(t));
         asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
+        stale |= touched;
         start = (uint32_t)t + 4u + ((about >> 26) & 15u);
-        t = first_set_or_minus_one(events & (~0ull << min(start, 63u))); // (bit 63 of events is never set)
-        about = read_lane(word_of_lane, t & 63);
+        about = pick();
       }
       // Their bytes, all at once: [literal tag, literals] copy element per
       // element, in lane order.  Where a lane's byte goes is a count of the

@@ -69,7 +69,7 @@ constexpr uint32_t kStraightMargin = 64 + 8 + 64 + 8;
 // words of lanes 0..kSpan+11, which come from the window before if the elements
 // moved on by no more than kStraightReach bytes
 #ifndef HC_SNAPPY_SPAN
-#define HC_SNAPPY_SPAN 40 // (measurement builds: 16..52)
+#define HC_SNAPPY_SPAN 52 // (measurement builds: 16..52; 32: 71.2, 40: 77.4, 48: 82.7, 52: 84.0 GB/s on text)
 #endif
 constexpr int kSpan = HC_SNAPPY_SPAN;
 constexpr uint32_t kStraightReach = 64; // (two registers of words: all 64 lanes of the next window are there)

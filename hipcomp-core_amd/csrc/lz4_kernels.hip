@@ -1637,41 +1637,47 @@ __device__ __forceinline__ bool far_straight_several(
       }
       return clash == 0 ? a : 0u;
     };
+    // the short sequences: which lanes they start and match at is all the loop notes
+    uint64_t match_lanes = 0, start_lanes = 0;
     uint32_t a = pick();
     while ((a >> 30) == 1u) {
-      const uint32_t lit = (uint32_t)f - start;
-      const uint32_t ml = (4u + ((a >> 26) & 15u)) / S; // elements
-      const uint32_t rel = (uint32_t)lane - start;
-      if (S == 1) {
-        // token, literals, offset in one store: the literal lanes write their own
-        // byte, the lane of the match the token, the two lanes behind it the offset
-        const uint32_t k = rel - lit - 1u;
-        const bool is_lit = rel < lit;
-        uint32_t val = is_lit ? word : (a & 0xFFFFu) >> (8u * k);
-        val = rel == lit ? (lit << 4) | (ml - 4u) : val;
-        const uint32_t off = rel == lit ? 0u : (is_lit ? rel + 1u : rel);
-        if (rel <= lit + 2u)
-          out[c + off] = (uint8_t)val;
-      } else {
-        // the literal lanes write their own element; the lane of the match the
-        // token, the two lanes behind it the offset
-        const uint32_t k = rel - lit - 1u;
-        if (rel < lit) {
-          if (S == 2)
-            *reinterpret_cast<HC_GLOBAL uint16_t __attribute__((aligned(1)))*>(out + c + 1u + rel * S) = (uint16_t)word;
-          else
-            *reinterpret_cast<HC_GLOBAL u32_unaligned*>(out + c + 1u + rel * S) = word;
-        }
-        const uint32_t val = rel == lit ? ((lit * S) << 4) | (ml * S - 4u) : (a & 0xFFFFu) >> (8u * k);
-        if (rel >= lit && rel <= lit + 2u)
-          out[c + (rel == lit ? 0u : lit * S + k + 1u)] = (uint8_t)val;
-      }
-      c += lit * S + 3u;
-      // insert the literal lanes (distinct slots)
-      far_store_masked(table, hpos, pos & 0xFFFFu, (1ull << f) - (1ull << start), lane);
+      asm("s_bitset1_b64 %0, %1" : "+s"(match_lanes) : "s"(f));
+      asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
       stale |= touched;
-      start = (uint32_t)f + ml;
+      start = (uint32_t)f + (4u + ((a >> 26) & 15u)) / S;
       a = pick();
+    }
+    // Their bytes, all at once: token, literals, offset per sequence, in lane
+    // order.  Where a lane's bytes go is a count of the lanes below it (literal
+    // lanes: S bytes each; sequences: 3 bytes each): every literal lane writes
+    // its own element, the match lane its sequence's token in front of the
+    // literals and the offset behind them.  The literal lanes go into the table
+    // (slots of their own, across the trip).
+    if (match_lanes != 0) {
+      const uint64_t lits = (match_lanes - start_lanes) & ~match_lanes; // lanes start..match-1 of every sequence
+      const bool is_match = ((match_lanes >> lane) & 1ull) != 0, is_lit = ((lits >> lane) & 1ull) != 0;
+      const uint32_t lits_below = __builtin_amdgcn_mbcnt_hi((uint32_t)(lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lits, 0u));
+      const uint32_t seqs_below = __builtin_amdgcn_mbcnt_hi((uint32_t)(match_lanes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)match_lanes, 0u));
+      // (behind the token and the literals below mine of my sequence)
+      const uint32_t at = c + lits_below * S + 3u * seqs_below + 1u;
+      if (is_lit) {
+        if (S == 1)
+          out[at] = (uint8_t)word;
+        else if (S == 2)
+          *reinterpret_cast<HC_GLOBAL uint16_t __attribute__((aligned(1)))*>(out + at) = (uint16_t)word;
+        else
+          *reinterpret_cast<HC_GLOBAL u32_unaligned*>(out + at) = word;
+      }
+      if (is_match) {
+        // my sequence starts at the highest start lane at or below me
+        const uint64_t upto = start_lanes & ((2ull << lane) - 1ull);
+        const uint32_t lit_mine = (uint32_t)lane - (63u - (uint32_t)__builtin_clzll(upto | 1ull));
+        const uint32_t match_bytes = ((4u + ((about >> 26) & 15u)) / S) * S;
+        out[at - 1u - lit_mine * S] = (uint8_t)(((lit_mine * S) << 4) | (match_bytes - 4u));
+        *reinterpret_cast<HC_GLOBAL uint16_t __attribute__((aligned(1)))*>(out + at) = (uint16_t)about;
+      }
+      far_store_masked(table, hpos, pos & 0xFFFFu, lits, lane);
+      c += (uint32_t)__builtin_popcountll(lits) * S + 3u * (uint32_t)__builtin_popcountll(match_lanes);
     }
     if ((a >> 30) == 3u) {
       // a match of 16 bytes or more ends the trip: its length from memory, the

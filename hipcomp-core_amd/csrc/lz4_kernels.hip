@@ -1556,7 +1556,7 @@ __device__ __forceinline__ bool far_straight(
 // stopped at had no table match among those lanes at all.
 // ---------------------------------------------------------------------------
 #ifndef HC_FAR_SPAN
-#define HC_FAR_SPAN 32 // (measurement builds; with two registers of words, bytes: 24: harness 57.4 / text 37.9 GB/s, 32: 59.0 / 38.4, 40: 60.3 / 38.2)
+#define HC_FAR_SPAN 40 // (measurement builds; bytes, 20 000 chunks: 32: harness 88 / text 38.5 GB/s, 40: 97 / 38.6, 48: 99.5 / 37.2)
 #endif
 constexpr int kFarSpan = HC_FAR_SPAN;
 
@@ -1573,18 +1573,13 @@ __device__ __forceinline__ bool far_straight_several(
     const uint32_t hmask, const uint32_t L, const uint32_t last_word, const int lane, uint32_t& d, uint32_t& c,
     uint32_t& token_start, int& cold, uint32_t& next)
 {
-  // lanes (= elements) the window's words can move down by: the path looks at
-  // the words of lanes 0 .. kFarSpan - 1 + 12 / S
-  // (byte elements keep two registers of words: the typed forms have no register to spare)
-  constexpr bool kTwoRegisters = S == 1;
-  constexpr uint32_t kReach = kTwoRegisters ? 64 : 64 - (kFarSpan + 12 / S);
+  // lanes (= elements) the window's words can move down by (two registers of words)
+  constexpr uint32_t kReach = 64;
   constexpr uint32_t kMostLiterals = 14 / S; // < 15 literal bytes: no length bytes
   uint32_t wnd = next;
   // (the 64 words behind the window's as well: the next window's words are then
   // there whatever the trip's sequences moved by)
-  uint32_t next_hi = 0;
-  if (kTwoRegisters)
-    next_hi = load_u32_any(in + (size_t)min(d + 64u + (uint32_t)lane, last_word) * S);
+  uint32_t next_hi = load_u32_any(in + (size_t)min(d + 64u + (uint32_t)lane, last_word) * S);
   bool armed = true;
   while (d + kFarFastMargin <= L) {
     const uint32_t word = wnd;
@@ -1697,18 +1692,14 @@ __device__ __forceinline__ bool far_straight_several(
     {
       const int from4 = (int)((((uint32_t)lane + moved) & 63u) * 4u);
       const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(from4, (int)next);
-      wnd = lo;
-      if (kTwoRegisters) {
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from4, (int)next_hi);
-        wnd = (uint32_t)lane + moved < 64u ? lo : hi;
-      }
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from4, (int)next_hi);
+      wnd = (uint32_t)lane + moved < 64u ? lo : hi;
     }
     d += moved;
     token_start = d;
     cold = 0;
     next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
-    if (kTwoRegisters)
-      next_hi = load_u32_any(in + (size_t)min(d + 64u + (uint32_t)lane, last_word) * S);
+    next_hi = load_u32_any(in + (size_t)min(d + 64u + (uint32_t)lane, last_word) * S);
     if (__builtin_expect(moved > kReach, 0)) {
       // (a real branch: as a select it would make every trip wait for the load)
       asm volatile("" ::: "memory");

@@ -239,39 +239,40 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
       // take without looking -- a short match, and no lane from its start to its
       // hit has a higher lane with its hash (so none of its lanes can clash with
       // anything).  While that holds an element costs the loop one v_readlane.
-      uint32_t follows;
+      const uint32_t after = (uint32_t)lane + 4u + ((word_of_lane >> 26) & 15u);
+      auto first_at_or_above = [&](uint64_t mask) -> uint32_t { // (per lane, from `after`; 127: none)
+        const uint64_t m = mask >> (after & 63u);
+        uint32_t lo, hi;
+        asm("v_ffbl_b32 %0, %1" : "=v"(lo) : "v"((uint32_t)m));
+        asm("v_ffbl_b32 %0, %1" : "=v"(hi) : "v"((uint32_t)(m >> 32)));
+        const uint32_t r = min(lo, hi | 32u);
+        return (after < 64u && r != ~0u) ? after + r : 127u;
+      };
+      const uint32_t next_hit = first_at_or_above(events);
+      bool easy;
       {
-        const uint32_t after = (uint32_t)lane + 4u + ((word_of_lane >> 26) & 15u);
-        auto first_at_or_above = [&](uint64_t mask) -> uint32_t { // (per lane, from `after`; 127: none)
-          const uint64_t m = mask >> (after & 63u);
-          uint32_t lo, hi;
-          asm("v_ffbl_b32 %0, %1" : "=v"(lo) : "v"((uint32_t)m));
-          asm("v_ffbl_b32 %0, %1" : "=v"(hi) : "v"((uint32_t)(m >> 32)));
-          const uint32_t r = min(lo, hi | 32u);
-          return (after < 64u && r != ~0u) ? after + r : 127u;
-        };
-        const uint32_t next_hit = first_at_or_above(events);
         const uint32_t next_sharing = first_at_or_above(sharing);
         const uint32_t next_word = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((next_hit & 63u) * 4u), (int)word_of_lane);
-        const bool easy = next_hit < 64u && (next_word >> 30) == 1u && next_sharing > next_hit;
-        follows = after | (next_hit << 7) | (easy ? 1u << 14 : 0u);
+        easy = next_hit < 64u && (next_word >> 30) == 1u && next_sharing > next_hit;
       }
+      uint32_t follows = after | (next_hit << 7) | (easy ? 1u << 14 : 0u);
       uint32_t about = pick();
       while ((about >> 30) == 1u) {
         asm("s_bitset1_b64 %0, %1" : "+s"(hit_lanes) : "s"(t));
         asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
-        stale |= touched;
+        if (touched != 0) {
+          // lanes with the hash of one just taken are no longer easy to pass
+          stale |= touched;
+          follows = after | (next_hit << 7) | ((easy && first_at_or_above(stale) > next_hit) ? 1u << 14 : 0u);
+        }
         uint32_t then = read_lane(follows, t);
         start = then & 127u; // (= t + 4 + copy length - 4)
-        if (stale == 0) {
-          // (nothing taken so far shares its hash with anything: the easy ones follow without a look)
-          while ((then & (1u << 14)) != 0) {
-            t = (int)((then >> 7) & 127u);
-            asm("s_bitset1_b64 %0, %1" : "+s"(hit_lanes) : "s"(t));
-            asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
-            then = read_lane(follows, t);
-            start = then & 127u;
-          }
+        while ((then & (1u << 14)) != 0) {
+          t = (int)((then >> 7) & 127u);
+          asm("s_bitset1_b64 %0, %1" : "+s"(hit_lanes) : "s"(t));
+          asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
+          then = read_lane(follows, t);
+          start = then & 127u;
         }
         about = pick();
       }

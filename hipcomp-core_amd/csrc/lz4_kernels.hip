@@ -1569,7 +1569,7 @@ __device__ __forceinline__ int first_set_or_minus_one(uint64_t m) // (s_ff1_i32_
 
 template <int S>
 __device__ __forceinline__ bool far_straight_several(
-    cgptr __restrict__ in, gptr __restrict__ out, HC_GLOBAL uint16_t* const table,
+    cgptr __restrict__ in, gptr __restrict__ out, HC_GLOBAL uint16_t* const table, uint16_t* const scr,
     const uint32_t hmask, const uint32_t L, const uint32_t last_word, const int lane, uint32_t& d, uint32_t& c,
     uint32_t& token_start, int& cold, uint32_t& next)
 {
@@ -1592,7 +1592,16 @@ __device__ __forceinline__ bool far_straight_several(
     // what a lane says about its table match, in one word: bit 30 set: there is
     // one, bit 31: of 16 bytes or more, 26-29 matching bytes - 4, 0-15 the offset in bytes
     uint32_t about = 0;
+    bool shares = false; // a higher lane (of the span) sits in my scratch slot, hence possibly in my table slot
     if (lane < kFarSpan) {
+      {
+        const uint32_t ks = hpos & (kFarScratchSlots - 1u);
+        lds_lane_exchange_fence();
+        scr[ks] = (uint16_t)lane; // (the highest lane of a slot stays)
+        lds_lane_exchange_fence();
+        shares = (uint32_t)scr[ks] != (uint32_t)lane;
+        lds_lane_exchange_fence();
+      }
       const uint32_t h_old = table[hpos];
       const uint32_t back = (pos - 1u - h_old) & 0xFFFFu; // (see window_candidate)
       const uint32_t cand = pos - 1u - back;
@@ -1632,14 +1641,53 @@ __device__ __forceinline__ bool far_straight_several(
       }
       return clash == 0 ? a : 0u;
     };
+    // What follows a match lane's sequence, for all lanes at once: bits 0-6
+    // where the next sequence's window starts, 7-13 its match lane (the first
+    // table match at or above that; 127: none), bit 14: that next sequence is
+    // one the loop can take without looking -- a short match, few enough
+    // literals, and none of its lanes (start .. match) has a higher lane in its
+    // scratch slot or sits in a slot a sequence of the trip has written: its
+    // literal lanes then have slots of their own, and what it looked up is still
+    // there.  While that holds a sequence costs the loop one v_readlane.
+    const uint64_t sharing = wave_ballot(shares);
+    const uint32_t after = (uint32_t)lane + (4u + ((about >> 26) & 15u)) / S;
+    auto first_at_or_above = [&](uint64_t mask) -> uint32_t { // (per lane, from `after`; 127: none)
+      const uint64_t m = mask >> (after & 63u);
+      uint32_t lo, hi;
+      asm("v_ffbl_b32 %0, %1" : "=v"(lo) : "v"((uint32_t)m));
+      asm("v_ffbl_b32 %0, %1" : "=v"(hi) : "v"((uint32_t)(m >> 32)));
+      const uint32_t r = min(lo, hi | 32u);
+      return (after < 64u && r != ~0u) ? after + r : 127u;
+    };
+    const uint32_t next_match = first_at_or_above(matches);
+    bool easy;
+    {
+      const uint32_t next_about = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((next_match & 63u) * 4u), (int)about);
+      // (a sequence without literals inserts nothing and has only its match lane to go stale)
+      easy = next_match < 64u && (next_about >> 30) == 1u && next_match - after <= kMostLiterals
+             && (next_match == after || first_at_or_above(sharing) > next_match);
+    }
+    uint32_t follows = after | (next_match << 7) | (easy ? 1u << 14 : 0u);
     // the short sequences: which lanes they start and match at is all the loop notes
     uint64_t match_lanes = 0, start_lanes = 0;
     uint32_t a = pick();
     while ((a >> 30) == 1u) {
       asm("s_bitset1_b64 %0, %1" : "+s"(match_lanes) : "s"(f));
       asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
-      stale |= touched;
-      start = (uint32_t)f + (4u + ((a >> 26) & 15u)) / S;
+      if (touched != 0) {
+        // lanes in the slots just written are no longer easy to pass
+        stale |= touched;
+        follows = after | (next_match << 7) | ((easy && first_at_or_above(stale) > next_match) ? 1u << 14 : 0u);
+      }
+      uint32_t then = read_lane(follows, f);
+      start = then & 127u; // (= f + match length)
+      while ((then & (1u << 14)) != 0) {
+        f = (int)((then >> 7) & 127u);
+        asm("s_bitset1_b64 %0, %1" : "+s"(match_lanes) : "s"(f));
+        asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
+        then = read_lane(follows, f);
+        start = then & 127u;
+      }
       a = pick();
     }
     // Their bytes, all at once: token, literals, offset per sequence, in lane
@@ -1768,7 +1816,7 @@ __device__ __forceinline__ void compress_wave_far(
         // form of this kernel)
         if (straight && token_start == d) {
           if (!WIDE)
-            straight = far_straight_several<S>(in, out, table, hmask, L, last_word, lane, d, c, token_start, cold, next);
+            straight = far_straight_several<S>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next);
           else
             straight = far_straight<S, WIDE>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next, 0);
         }

@@ -1559,6 +1559,7 @@ __device__ __forceinline__ bool far_straight(
 #define HC_FAR_SPAN 40 // (measurement builds; bytes, 20 000 chunks: 32: harness 88 / text 38.5 GB/s, 40: 97 / 38.6, 48: 99.5 / 37.2)
 #endif
 constexpr int kFarSpan = HC_FAR_SPAN;
+constexpr int kFarSpanMost = 52; // (the words 12 bytes on of its lanes are still in the window)
 
 __device__ __forceinline__ int first_set_or_minus_one(uint64_t m) // (s_ff1_i32_b64 as it is)
 {
@@ -1571,7 +1572,7 @@ template <int S>
 __device__ __forceinline__ bool far_straight_several(
     cgptr __restrict__ in, gptr __restrict__ out, HC_GLOBAL uint16_t* const table, uint16_t* const scr,
     const uint32_t hmask, const uint32_t L, const uint32_t last_word, const int lane, uint32_t& d, uint32_t& c,
-    uint32_t& token_start, int& cold, uint32_t& next)
+    uint32_t& token_start, int& cold, uint32_t& next, const uint32_t span)
 {
   // lanes (= elements) the window's words can move down by (two registers of words)
   constexpr uint32_t kReach = 64;
@@ -1593,7 +1594,7 @@ __device__ __forceinline__ bool far_straight_several(
     // one, bit 31: of 16 bytes or more, 26-29 matching bytes - 4, 0-15 the offset in bytes
     uint32_t about = 0;
     bool shares = false; // a higher lane (of the span) sits in my scratch slot, hence possibly in my table slot
-    if (lane < kFarSpan) {
+    if ((uint32_t)lane < span) {
       {
         const uint32_t ks = hpos & (kFarScratchSlots - 1u);
         lds_lane_exchange_fence();
@@ -1624,7 +1625,7 @@ __device__ __forceinline__ bool far_straight_several(
     int f;
     uint64_t touched;
     auto pick = [&]() -> uint32_t {
-      f = first_set_or_minus_one(matches & (~0ull << start)); // (start <= kFarSpan - 1 + 15)
+      f = first_set_or_minus_one(matches & (~0ull << min(start, 63u))); // (start <= span - 1 + 15; bit 63 of matches is never set)
       const uint32_t lit = (uint32_t)f - start; // (no match: huge)
       if (lit > kMostLiterals)
         return 0u;
@@ -1768,7 +1769,8 @@ __device__ __forceinline__ void compress_wave_far(
     uint16_t* const scr,
     const uint32_t batch,
     uint32_t* __restrict__ ticket,
-    const uint32_t chunks_per_ticket)
+    const uint32_t chunks_per_ticket,
+    const uint32_t span)
 {
   constexpr uint32_t LVM = (12 + S - 1) / S;
   constexpr int NVMAX = kWave - 3 / S;
@@ -1816,7 +1818,7 @@ __device__ __forceinline__ void compress_wave_far(
         // form of this kernel)
         if (straight && token_start == d) {
           if (!WIDE)
-            straight = far_straight_several<S>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next);
+            straight = far_straight_several<S>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next, span);
           else
             straight = far_straight<S, WIDE>(in, out, table, scr, hmask, L, last_word, lane, d, c, token_start, cold, next, 0);
         }
@@ -1898,12 +1900,18 @@ __global__ __launch_bounds__(kFarWavesPerGroup * kWave, kFarGroupsPerCu) void lz
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // kFarScratchSlots x u16 per wave
   if (mode && sampled_mode(mode) != (WIDE ? kModeFarWide : kModeFar))
     return;
+  // lanes a trip of the lean form looks up: more when nearly every sampled word
+  // repeated (short sequences, issue slots the limit: harness 126 -> 146 GB/s),
+  // fewer otherwise (text is bound by the lines a trip pulls in: 38.5 vs 37.3)
+  uint32_t span = kFarSpan;
+  if (mode && uniform(mode[0]) * 8u > uniform(mode[1]) * 7u)
+    span = kFarSpanMost;
   const uint32_t wave = uniform((uint32_t)(threadIdx.x >> 6));
   const size_t gw = (size_t)blockIdx.x * kFarWavesPerGroup + wave;
   compress_wave_far<S, WIDE>(in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size,
                        (HC_GLOBAL uint16_t*)(tables + gw * max(ht_size, 8u)), // (16 bytes at least: filled 16 at a time)
                        reinterpret_cast<uint16_t*>(smem) + wave * kFarScratchSlots, batch, ticket,
-                       chunks_per_ticket);
+                       chunks_per_ticket, span);
 }
 
 // Which shape suits the data: kSampleChunks chunks spread over the batch (one

@@ -156,6 +156,47 @@ def test_several_sequences_per_trip_corner_cases(hc, oracle, reflib, cuda, tname
     assert dec.to_host_chunks() == chunks
 
 
+@pytest.mark.parametrize("tname,dtype,es", TYPES)
+def test_most_repetitive_batches_take_the_widest_span(hc, oracle, reflib, cuda, tname, dtype, es):
+    """When nearly every sampled word repeats (the harness's data, short periods,
+    tiny alphabets) the far shape's lean form looks up 52 lanes per trip instead
+    of 40: checked that the sampler says so, then every chunk against the oracle
+    and the reference build, and the round trip."""
+    import torch
+    base = []
+    for k in range(16):
+        base.append(datagen.harness_like_int32(700 + k, 16384 - 5 * k).tobytes())
+    for i, p in enumerate((1, 2, 3, 4, 5, 7, 8, 12, 16, 24)):
+        base.append(datagen.periodic_bytes(720 + i, 65536 - 9 * i, p, 50 + 7 * i))
+    for i, sy in enumerate((2, 2, 3, 3, 4, 4)):
+        base.append(datagen.small_alphabet_bytes(740 + i, 65536 - 11 * i, sy))
+    base = [c[: len(c) // es * es] for c in base]
+    assert len(base) == 32
+    chunks = base * 48
+    want = [oracle.lz4_compress(c, es, 65536) for c in base]
+    src = hc.batch.from_host_chunks(chunks, "cuda:0")
+    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
+    dst = hc.batch.alloc_batch(src.n, codec.max_output_chunk_size(65536), src.device)
+    temp = torch.zeros((codec.compress_temp_size(src.n, 65536),), dtype=torch.uint8, device=src.device)
+    assert codec.compress_async(src, 65536, temp, dst) == 0
+    torch.cuda.synchronize()
+    ticket, repeats, looked = temp[:12].view(torch.int32).cpu().tolist()
+    if os.environ.get("HIPCOMP_LZ4_SHAPE", "auto") == "auto":
+        assert looked > 0 and repeats * 8 > looked * 7
+    got = dst.to_host_chunks()
+    for i in range(len(chunks)):
+        assert got[i] == want[i % len(base)], f"chunk {i} {tname}: kernel != oracle"
+    if reflib is not None:
+        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=reflib).compress(src, 65536)
+        torch.cuda.synchronize()
+        refgot = ref.to_host_chunks()
+        for i in range(len(base)):
+            assert refgot[i] == want[i], f"chunk {i} {tname}: oracle != reference"
+    dec, actual, statuses = codec.decompress(dst, 65536)
+    assert statuses.cpu().tolist() == [0] * len(chunks)
+    assert dec.to_host_chunks() == chunks
+
+
 def test_small_tables_many_waves_per_group(hc, oracle, cuda):
     """max_chunk below 16 KiB: smaller hash tables, up to 16 waves (= chunks
     in flight) per workgroup, batch sizes that do not fill the last group."""

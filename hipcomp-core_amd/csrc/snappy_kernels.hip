@@ -557,9 +557,9 @@ __global__ __launch_bounds__(256) void snappy_get_sizes_kernel(
 constexpr int kDecompWavesPerBlock = 4;
 
 // How far past an element's tag the decoder looks in the register window
-// before it asks for the window again: the tag and the 60 literal bytes or the
-// offset bytes behind it.
-constexpr uint32_t kSnappyWindowReach = 64;
+// before it asks for the window again: in the several-elements step elements
+// start within 64 bytes of the first one's tag and reach up to 61 bytes further.
+constexpr uint32_t kSnappyBatchReach = 128;
 // Least bytes of stream left for the window to be used (tag + 3).
 constexpr uint32_t kSnappyWindowMin = 4;
 
@@ -575,6 +575,7 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
   // literal << 16 | 1-byte-offset copy << 17 | not for the fast path << 31
   // (4-byte offset, literal with a length field).
   __shared__ uint32_t tag_lut[256];
+  __shared__ uint8_t rank_to_lane[kDecompWavesPerBlock][kWave]; // (the several-elements step below)
   static_assert(kWave * kDecompWavesPerBlock == 256, "one tag per thread");
   {
     const uint32_t b = threadIdx.x, kind = b & 3u, n6 = b >> 2;
@@ -631,7 +632,74 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
           const uint32_t avail = end - vcur; // (cur <= end always)
           if (wave_ballot((int32_t)((vleft - 1u) | (avail - kSnappyWindowMin)) < 0) != 0)
             break;
-          sw.ensure(comp, vcur, end, kSnappyWindowReach, lane);
+          // ---- several elements as one step: lane i looks at the stream byte i
+          // bytes on as if an element started there (what it says: the table);
+          // the elements that do start are followed from the first one (one
+          // v_readlane each) for as long as they are of this path's kinds and
+          // their output fits 64 bytes; then every output byte finds its element
+          // (the highest output start at or below it; its stream lane through a
+          // small table in LDS) and its source: the stream window for literals,
+          // out[] for copies -- whose source has to lie in front of the step's
+          // output, or the step ends in front of that copy.
+          sw.ensure(comp, vcur, end, kSnappyBatchReach, lane);
+          {
+            const uint32_t ib = vcur - sw.base;
+            const uint32_t w_here = sw.bytes_at(ib + i);
+            const uint32_t e_here = tag_lut[w_here & 0xFFu];
+            // need | output bytes << 8 | of this path's kinds << 16
+            const uint32_t says = ((e_here >> 8) & 0xFFu) | ((e_here & 0xFFu) << 8) | ((e_here >> 31) ? 0u : 1u << 16);
+            const uint32_t avail_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)avail);
+            const uint32_t room = min((uint32_t)__builtin_amdgcn_readfirstlane((int)vleft), (uint32_t)kWave);
+            uint32_t at = 0, total = 0, count = 0;
+            uint64_t stream_starts = 0, out_starts = 0;
+            uint32_t p = read_lane(says, 0);
+            while ((p >> 16) != 0 && total + ((p >> 8) & 0xFFu) <= room && at + (p & 0xFFu) <= avail_s) {
+              asm("s_bitset1_b64 %0, %1" : "+s"(stream_starts) : "s"(at));
+              asm("s_bitset1_b64 %0, %1" : "+s"(out_starts) : "s"(total));
+              total += (p >> 8) & 0xFFu;
+              at += p & 0xFFu;
+              ++count;
+              p = at < (uint32_t)kWave ? read_lane(says, (int)(at & 63u)) : 0u;
+            }
+            if (count >= 2) {
+              const int wave_in_block = (int)(threadIdx.x >> 6);
+              if ((stream_starts >> i) & 1ull)
+                rank_to_lane[wave_in_block][lanes_set_below(stream_starts)] = (uint8_t)i;
+              lds_lane_exchange_fence();
+              const uint64_t upto = out_starts & ((2ull << i) - 1ull);
+              const uint32_t o_mine = 63u - (uint32_t)__builtin_clzll(upto | 1ull); // where my element's output starts
+              const uint32_t rank = lanes_set_below(out_starts) + (uint32_t)((out_starts >> i) & 1ull) - 1u;
+              const uint32_t t_mine = rank_to_lane[wave_in_block][rank & 63u];        // its stream lane
+              lds_lane_exchange_fence();
+              const uint32_t w_mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t_mine * 4u), (int)w_here);
+              const uint32_t e_mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t_mine * 4u), (int)e_here);
+              const bool lit_mine = (e_mine & (1u << 16)) != 0u;
+              const uint32_t blen_mine = e_mine & 0xFFu;
+              const uint32_t o16 = (w_mine >> 8) & 0xFFFFu;
+              const uint32_t offset_mine = (e_mine & (1u << 17)) ? ((w_mine & 0xe0u) << 3) | (o16 & 0xFFu) : o16;
+              // a copy: its source in front of the step's output (which says offset != 0), offset <= dst
+              const uint32_t bad_mine = lit_mine ? 0u : (offset_mine - (o_mine + blen_mine)) | (vdst + o_mine - offset_mine);
+              const uint64_t bad_lanes = wave_ballot(i < total && (int32_t)bad_mine < 0);
+              if (bad_lanes != 0) { // the step ends in front of the first such copy
+                const int b = __builtin_ctzll(bad_lanes);
+                total = read_lane(o_mine, b);
+                at = read_lane(t_mine, b);
+              }
+              if (total != 0) {
+                const uint32_t widx = ib + t_mine + 1u + (i - o_mine);
+                const uint32_t wword = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(widx & ~3u), (int)sw.words);
+                if (i < total) {
+                  // (a literal's lanes load their own destination byte: inside the buffer, value unused)
+                  const uint32_t ob = static_cast<cgptr>(out)[lit_mine ? vdst + i : vdst + i - offset_mine];
+                  out[vdst + i] = (uint8_t)(lit_mine ? wword >> ((widx & 3u) * 8u) : ob);
+                }
+                vcur += at;
+                vdst += total;
+                vleft -= total;
+                continue;
+              }
+            }
+          }
           const uint32_t t = sw.bytes_at(vcur - sw.base);
           const uint32_t e = tag_lut[t & 0xFFu];
           const uint32_t blen = e & 0xFFu, need = (e >> 8) & 0xFFu;

@@ -2003,6 +2003,10 @@ __device__ __forceinline__ bool read_lsic(
 // Bytes the decoder's fast path may touch from the token on: token, up to 14
 // literals, 2 offset bytes, one match length byte.
 constexpr uint32_t kFastSeqBytes = 18;
+// The several-sequences step looks at tokens up to 63 bytes on and at what they
+// need behind them.
+constexpr uint32_t kBatchReach = 64 + kFastSeqBytes;
+constexpr uint32_t kBatchRest = 16;
 
 template <bool WRITE_OUT>
 __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_kernel(
@@ -2014,6 +2018,7 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
     size_t* __restrict__ actual_bytes,
     hipcompStatus_t* __restrict__ statuses)
 {
+  __shared__ uint8_t rank_to_lane[kDecompWavesPerBlock][kWave]; // (the several-sequences step)
   const int lane = lane_id();
   // everything that steers the parse is wave-uniform: say so (see uniform())
   const size_t chunk
@@ -2043,6 +2048,10 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
   // (StreamWindow), i.e. without a memory round trip in the chain that leads
   // from one token to the next.
   StreamWindow sw;
+  // sequences to go before the several-sequences step is tried again: twice as
+  // many after every try that took nothing (data of long matches never has two
+  // short sequences in a row), none after one that did
+  uint32_t batch_rest = 0, batch_fails = 0;
   for (;;) {
     uint32_t tok = 0;
     // ---- fast paths: token, up to 14 literals, offset and at most one match
@@ -2050,8 +2059,95 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
     // byte per lane).  The loop is left at the first sequence that is anything
     // else: it takes the general path below.
     while (c + kFastSeqBytes <= end) {
-      sw.ensure(comp, c, end, kFastSeqBytes, lane);
+      sw.ensure(comp, c, end, kBatchReach, lane);
       const uint32_t idx = c - sw.base;
+      // ---- several sequences as one step: lane i looks at the stream byte i
+      // bytes on as if a token stood there; the sequences that do start are
+      // followed from the first one (one v_readlane each) for as long as they
+      // are short ones (lengths in the token, all of it inside the stream as
+      // the fast paths below ask) and their output fits 64 bytes and the
+      // buffer; then every output byte finds its sequence (the highest output
+      // start at or below it; its stream lane through a small table in LDS) and
+      // its source: the stream window for literals, out[] for matches -- whose
+      // source has to lie in front of the step's output (which also says
+      // offset != 0 and that it does not overlap), or the step ends in front
+      // of that sequence.
+      if (batch_rest != 0) {
+        --batch_rest;
+      } else {
+        batch_rest = min((1u << batch_fails) - 1u, kBatchRest); // (undone below if the step takes something)
+        batch_fails = min(batch_fails + 1u, 5u);
+        const uint32_t i = (uint32_t)lane;
+        auto window_bytes = [&](uint32_t at) -> uint32_t { // 4 bytes at byte index `at` (per lane) of the window
+          const uint32_t q4 = at & ~3u;
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)q4, (int)sw.words);
+          const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q4 + 4u), (int)sw.words);
+          return __builtin_amdgcn_alignbyte(hi, lo, at & 3u);
+        };
+        const uint32_t w_here = window_bytes(idx + i);
+        const uint32_t lit_here = (w_here >> 4) & 15u, mlc_here = w_here & 15u;
+        const uint32_t off_here = window_bytes(idx + i + 1u + lit_here) & 0xFFFFu;
+        // stream bytes | output bytes << 8 | a short one << 16
+        const uint32_t says = (3u + lit_here) | ((lit_here + mlc_here + 4u) << 8)
+                              | ((lit_here < 15u && mlc_here < 15u) ? 1u << 16 : 0u);
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)vd);
+        const uint32_t room = min(capc - min(d0, capc), (uint32_t)kWave);
+        const uint32_t last_start = end - c - kFastSeqBytes; // (tokens up to here are the fast paths')
+        uint32_t at = 0, total = 0, count = 0;
+        uint64_t stream_starts = 0, out_starts = 0;
+        uint32_t p = read_lane(says, 0);
+        while ((p >> 16) != 0 && total + ((p >> 8) & 0xFFu) <= room && at <= last_start) {
+          asm("s_bitset1_b64 %0, %1" : "+s"(stream_starts) : "s"(at));
+          asm("s_bitset1_b64 %0, %1" : "+s"(out_starts) : "s"(total));
+          total += (p >> 8) & 0xFFu;
+          at += p & 0xFFu;
+          ++count;
+          p = at < (uint32_t)kWave ? read_lane(says, (int)(at & 63u)) : 0u;
+        }
+        if (count >= 2) {
+          const int wave_in_block = (int)(threadIdx.x >> 6);
+          if ((stream_starts >> i) & 1ull)
+            rank_to_lane[wave_in_block][__builtin_amdgcn_mbcnt_hi((uint32_t)(stream_starts >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)stream_starts, 0u))]
+                = (uint8_t)i;
+          lds_lane_exchange_fence();
+          const uint64_t upto = out_starts & ((2ull << i) - 1ull);
+          const uint32_t o_mine = 63u - (uint32_t)__builtin_clzll(upto | 1ull); // where my sequence's output starts
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(out_starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)out_starts, 0u))
+                                + (uint32_t)((out_starts >> i) & 1ull) - 1u;
+          const uint32_t t_mine = rank_to_lane[wave_in_block][rank & 63u]; // its stream lane
+          lds_lane_exchange_fence();
+          const uint32_t w_mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t_mine * 4u), (int)w_here);
+          const uint32_t off_mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t_mine * 4u), (int)off_here);
+          const uint32_t lit_mine = (w_mine >> 4) & 15u, ml_mine = (w_mine & 15u) + 4u;
+          // the match: its source in front of the step's output, inside what exists
+          const uint32_t bad_mine = (off_mine - (o_mine + lit_mine + ml_mine)) | (d0 + o_mine + lit_mine - off_mine);
+          const uint64_t bad_lanes = wave_ballot(i < total && (int32_t)bad_mine < 0);
+          if (bad_lanes != 0) { // the step ends in front of the first such sequence
+            const int b = __builtin_ctzll(bad_lanes);
+            total = read_lane(o_mine, b);
+            at = read_lane(t_mine, b);
+          }
+          if (total != 0) {
+            if (WRITE_OUT) {
+              const uint32_t k = i - o_mine;
+              const uint32_t widx = idx + t_mine + 1u + k;
+              const uint32_t wword = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(widx & ~3u), (int)sw.words);
+              if (i < total) {
+                // (a literal's lane loads its own destination byte: inside the buffer, value unused)
+                const bool literal = k < lit_mine;
+                const uint32_t gb = static_cast<cgptr>(out)[literal ? d0 + i : d0 + i - off_mine];
+                out[d0 + i] = (uint8_t)(literal ? wword >> ((widx & 3u) * 8u) : gb);
+              }
+            }
+            c += at;
+            vd += total;
+            batch_rest = 0;
+            batch_fails = 0;
+            continue;
+          }
+        }
+      }
       const uint32_t tw = read_lane(sw.words, (int)(idx >> 2)) >> ((idx & 3u) * 8u); // token = low byte
       tok = tw & 0xFFu;
       const uint32_t litf = (tw >> 4) & 15u;

@@ -625,6 +625,7 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
       uint32_t vleft = in_vector_register(usize);
       const uint32_t i = (uint32_t)lane;
       StreamWindowV sw;
+      uint32_t batch_rest = 0, batch_fails = 0; // (the several-elements step below)
       for (;;) {
         // ---- elements with a one-byte length: literals of up to 60 bytes,
         // copies with 1- and 2-byte offsets, at least 4 bytes of stream left
@@ -642,7 +643,13 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
           // out[] for copies -- whose source has to lie in front of the step's
           // output, or the step ends in front of that copy.
           sw.ensure(comp, vcur, end, kSnappyBatchReach, lane);
-          {
+          // (tried again after twice as many elements every time it took nothing,
+          // at once after it did: long literals and copies never come two to a step)
+          if (batch_rest != 0) {
+            --batch_rest;
+          } else {
+            batch_rest = min((1u << batch_fails) - 1u, 15u);
+            batch_fails = min(batch_fails + 1u, 5u);
             const uint32_t ib = vcur - sw.base;
             const uint32_t w_here = sw.bytes_at(ib + i);
             const uint32_t e_here = tag_lut[w_here & 0xFFu];
@@ -696,6 +703,8 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
                 vcur += at;
                 vdst += total;
                 vleft -= total;
+                batch_rest = 0;
+                batch_fails = 0;
                 continue;
               }
             }

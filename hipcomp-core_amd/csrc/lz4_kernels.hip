@@ -2119,9 +2119,9 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
           lds_lane_exchange_fence();
           const uint32_t w_mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t_mine * 4u), (int)w_here);
           const uint32_t off_mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t_mine * 4u), (int)off_here);
-          const uint32_t lit_mine = (w_mine >> 4) & 15u, ml_mine = (w_mine & 15u) + 4u;
-          // the match: its source in front of the step's output, inside what exists
-          const uint32_t bad_mine = (off_mine - (o_mine + lit_mine + ml_mine)) | (d0 + o_mine + lit_mine - off_mine);
+          const uint32_t lit_mine = (w_mine >> 4) & 15u;
+          // the match: 0 < offset <= what exists in front of it
+          const uint32_t bad_mine = (off_mine - 1u) | (d0 + o_mine + lit_mine - off_mine);
           const uint64_t bad_lanes = wave_ballot(i < total && (int32_t)bad_mine < 0);
           if (bad_lanes != 0) { // the step ends in front of the first such sequence
             const int b = __builtin_ctzll(bad_lanes);
@@ -2133,12 +2133,27 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void lz4_decompress_k
               const uint32_t k = i - o_mine;
               const uint32_t widx = idx + t_mine + 1u + k;
               const uint32_t wword = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(widx & ~3u), (int)sw.words);
-              if (i < total) {
-                // (a literal's lane loads its own destination byte: inside the buffer, value unused)
-                const bool literal = k < lit_mine;
-                const uint32_t gb = static_cast<cgptr>(out)[literal ? d0 + i : d0 + i - off_mine];
-                out[d0 + i] = (uint8_t)(literal ? wword >> ((widx & 3u) * 8u) : gb);
+              // A byte comes from the stream window (literal), from out[] in front of
+              // the step (a match that reaches back that far), or from a lower lane of
+              // this very step -- which may have its byte from a lower lane again
+              // (matches of matches, matches that overlap themselves).  Every lane
+              // keeps the lane its byte comes from; six rounds of "take the source's
+              // source" (chains halve each round) bring all of them to a lane of
+              // the first two kinds.
+              const bool literal = k < lit_mine;
+              const int32_t from_rel = (int32_t)(i - off_mine); // (match lanes) < 0: in front of the step
+              const bool outside = i >= total || literal || from_rel < 0;
+              uint32_t val = wword >> ((widx & 3u) * 8u);
+              if (i < total && !literal && from_rel < 0)
+                val = static_cast<cgptr>(out)[d0 + (uint32_t)from_rel];
+              uint32_t from = outside ? (i | 0x80u) : (uint32_t)from_rel; // bit 7: a lane that has its byte
+              while (wave_ballot((from & 0x80u) == 0u) != 0) {
+                const uint32_t theirs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((from & 63u) * 4u), (int)from);
+                from = (from & 0x80u) ? from : theirs;
               }
+              val = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((from & 63u) * 4u), (int)val);
+              if (i < total)
+                out[d0 + i] = (uint8_t)val;
             }
             c += at;
             vd += total;

@@ -681,11 +681,10 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
               const uint32_t w_mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t_mine * 4u), (int)w_here);
               const uint32_t e_mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t_mine * 4u), (int)e_here);
               const bool lit_mine = (e_mine & (1u << 16)) != 0u;
-              const uint32_t blen_mine = e_mine & 0xFFu;
               const uint32_t o16 = (w_mine >> 8) & 0xFFFFu;
               const uint32_t offset_mine = (e_mine & (1u << 17)) ? ((w_mine & 0xe0u) << 3) | (o16 & 0xFFu) : o16;
-              // a copy: its source in front of the step's output (which says offset != 0), offset <= dst
-              const uint32_t bad_mine = lit_mine ? 0u : (offset_mine - (o_mine + blen_mine)) | (vdst + o_mine - offset_mine);
+              // a copy: 0 < offset <= dst
+              const uint32_t bad_mine = lit_mine ? 0u : (offset_mine - 1u) | (vdst + o_mine - offset_mine);
               const uint64_t bad_lanes = wave_ballot(i < total && (int32_t)bad_mine < 0);
               if (bad_lanes != 0) { // the step ends in front of the first such copy
                 const int b = __builtin_ctzll(bad_lanes);
@@ -695,11 +694,26 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
               if (total != 0) {
                 const uint32_t widx = ib + t_mine + 1u + (i - o_mine);
                 const uint32_t wword = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(widx & ~3u), (int)sw.words);
-                if (i < total) {
-                  // (a literal's lanes load their own destination byte: inside the buffer, value unused)
-                  const uint32_t ob = static_cast<cgptr>(out)[lit_mine ? vdst + i : vdst + i - offset_mine];
-                  out[vdst + i] = (uint8_t)(lit_mine ? wword >> ((widx & 3u) * 8u) : ob);
+                // A byte comes from the stream window (literal), from out[] in front
+                // of the step (a copy that reaches back that far), or from a lower
+                // lane of this very step -- which may have its byte from a lower lane
+                // again (copies of copies, copies that overlap themselves).  Every
+                // lane keeps the lane its byte comes from; rounds of "take the
+                // source's source" (chains halve each round) bring all of them to a
+                // lane of the first two kinds.
+                const int32_t from_rel = (int32_t)(i - offset_mine); // (copy lanes) < 0: in front of the step
+                const bool outside = i >= total || lit_mine || from_rel < 0;
+                uint32_t val = wword >> ((widx & 3u) * 8u);
+                if (i < total && !lit_mine && from_rel < 0)
+                  val = static_cast<cgptr>(out)[vdst + (uint32_t)from_rel];
+                uint32_t from = outside ? (i | 0x80u) : (uint32_t)from_rel; // bit 7: a lane that has its byte
+                while (wave_ballot((from & 0x80u) == 0u) != 0) {
+                  const uint32_t theirs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((from & 63u) * 4u), (int)from);
+                  from = (from & 0x80u) ? from : theirs;
                 }
+                val = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((from & 63u) * 4u), (int)val);
+                if (i < total)
+                  out[vdst + i] = (uint8_t)val;
                 vcur += at;
                 vdst += total;
                 vleft -= total;

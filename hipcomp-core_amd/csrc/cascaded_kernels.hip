@@ -66,18 +66,22 @@ __host__ __device__ constexpr uint32_t wave_lds_bytes()
 }
 
 // decoder: the head of the compressed sub-chunk (metadata + arrays) is staged
-// in LDS, kStageWords 32-bit words, kStagePerLane per lane, loaded one
+// in LDS, stage_words<CB>() 32-bit words, stage_per_lane<CB>() per lane, loaded one
 // sub-chunk ahead into registers.  Arrays that do not fit are read from HBM
 // directly.  1 KiB holds the whole sub-chunk of a column that compresses 4x or
 // better and lets a CU hold 14 waves of the 4-byte / 4096 launch (2 KiB: 12;
 // measured 960 vs 843 GB/s at ratio 5.3, 770 vs 840 GB/s at ratio 2.2).
-constexpr uint32_t kStagePerLane = 4;
-constexpr uint32_t kStageWords = kStagePerLane * kWave; // 1 KiB
+// (per 4096 bytes of sub-chunk; the larger sub-chunks stage 2 and 4 KiB, which costs
+// their launches no resident wave)
+template <int CB>
+__host__ __device__ constexpr uint32_t stage_per_lane() { return 4u * (CB / 4096); }
+template <int CB>
+__host__ __device__ constexpr uint32_t stage_words() { return stage_per_lane<CB>() * kWave; }
 template <int S, int CB>
 __host__ __device__ constexpr uint32_t dec_lds_bytes()
 {
   // two element buffers + run markers + staged sub-chunk
-  return 2 * elem_buf_bytes<CB>() + (CB / S) * 2 + kStageWords * 4;
+  return 2 * elem_buf_bytes<CB>() + (CB / S) * 2 + stage_words<CB>() * 4;
 }
 
 // ---- wave reductions (64 lanes) -------------------------------------------
@@ -515,7 +519,7 @@ struct ArrayReader {
 // Array at byte offset `rel` of the sub-chunk that starts at comp + pos:
 // bounds as in the reference (:712-713), source = staged image when the array
 // lies inside it.
-template <typename ET>
+template <typename ET, uint32_t STAGE_WORDS>
 __device__ __forceinline__ int wave_read_array(
     cgptr comp, uint32_t end_words, uint32_t pos, uint32_t rel, uint32_t nbytes,
     int bp, const uint32_t* stage, ET* dst, uint32_t max_elems, int lane)
@@ -523,7 +527,7 @@ __device__ __forceinline__ int wave_read_array(
   const uint32_t off = pos + rel;
   if ((off & 3u) || (off + ru(nbytes, 4)) / 4 > end_words)
     return -1;
-  if (rel + ru(nbytes, 4) <= kStageWords * 4)
+  if (rel + ru(nbytes, 4) <= STAGE_WORDS * 4)
     return unpack_array<ET>(stage + rel / 4, nbytes, bp, dst, max_elems, lane);
   return unpack_array<ET>(reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off), nbytes, bp, dst,
                           max_elems, lane);
@@ -639,14 +643,14 @@ __device__ __forceinline__ void cascaded_decode_partition(
   const int layers = R > D ? R : D;
   uint32_t pos = ru(kPartMeta, S), done = 0;
   bool ok = true;
-  // kStageWords words of the sub-chunk at `p`, kStagePerLane per lane, clipped to the
+  // stage_words<CB>() words of the sub-chunk at `p`, stage_per_lane<CB>() per lane, clipped to the
   // partition (words past the end read as 0); issued one sub-chunk ahead
-  uint32_t pf[kStagePerLane];
+  uint32_t pf[stage_per_lane<CB>()];
   auto prefetch = [&](uint32_t p) {
     const HC_GLOBAL uint32_t* w = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + p);
     const uint32_t avail = end_w - p / 4;
 #pragma unroll
-    for (int k = 0; k < (int)kStagePerLane; ++k) {
+    for (int k = 0; k < (int)stage_per_lane<CB>(); ++k) {
       const uint32_t idx = (uint32_t)lane + (uint32_t)k * kWave;
       pf[k] = w[min(idx, avail - 1)];
     }
@@ -659,7 +663,7 @@ __device__ __forceinline__ void cascaded_decode_partition(
       break;
     }
 #pragma unroll
-    for (int k = 0; k < (int)kStagePerLane; ++k)
+    for (int k = 0; k < (int)stage_per_lane<CB>(); ++k)
       stage[lane + k * kWave] = pf[k];
     const uint32_t csz = uniform(meta[0]);
     // A sub-chunk has to lie inside the partition and to move the cursor on:
@@ -685,7 +689,7 @@ __device__ __forceinline__ void cascaded_decode_partition(
     }
     UT* x = bufA;
     UT* y = bufB;
-    int n = wave_read_array<UT>(comp, end_w, pos, msz + offs_final, uniform(meta[1 + R]), bp, stage, x, CE, lane);
+    int n = wave_read_array<UT, stage_words<CB>()>(comp, end_w, pos, msz + offs_final, uniform(meta[1 + R]), bp, stage, x, CE, lane);
     if (n < 0) {
       ok = false;
       break;
@@ -767,7 +771,7 @@ __device__ __forceinline__ void cascaded_decode_partition(
           const uint32_t off = pos + rel;
           bool good = !((off & 3u) || (off + ru(nbytes, 4)) / 4 > end_w);
           if (good) {
-            if (rel + ru(nbytes, 4) <= kStageWords * 4)
+            if (rel + ru(nbytes, 4) <= stage_words<CB>() * 4)
               good = run_starts(static_cast<const uint32_t*>(stage + rel / 4));
             else
               good = run_starts(reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off));

@@ -1397,7 +1397,113 @@ __device__ __forceinline__ bool far_straight(
   if (WIDE)
     next_hi = load_u32_any(in + (size_t)min(d + 64u + (uint32_t)lane, last_word) * S);
   bool armed = true;
+  uint32_t runs_rest = 0, runs_fails = 0; // (the runs trip below: tried again after twice as many windows when it took nothing)
   while (d + kFarFastMargin <= L) {
+    // ---- Wide, 4-byte elements, runs of values never seen before (a column of
+    // run-length data): every sequence is "one literal element, then the rest of
+    // its run as a match against the lane below", and one trip to the table
+    // settles all of them inside kRunSpan lanes -- provided no lane there has a
+    // table candidate, and every lane that shares its scratch slot (hence
+    // possibly its table slot, or its word) with a higher lane does so only
+    // inside the run of equal words it stands in: then the first lane of a window
+    // with an equal lower lane is the second lane of its first run, the lower
+    // lane is the one right below, and the match is as long as the run.  The
+    // sequences come off the mask of "equal to the lane below" with scalar bit
+    // operations and are written at once as in far_straight_several.
+    if (WIDE && S == 4) {
+      if (runs_rest != 0) {
+        --runs_rest;
+      } else {
+        runs_rest = min((1u << runs_fails) - 1u, 15u);
+        runs_fails = min(runs_fails + 1u, 5u);
+        constexpr uint32_t kRunSpan = 48;
+        const uint32_t word = wnd;
+        const uint32_t hpos = hash_sum(word) & hmask;
+        const uint32_t pos = d + (uint32_t)lane;
+        const uint32_t below_word = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane - 1u) & 63u) * 4u), (int)word);
+        const uint64_t same_below = wave_ballot(lane > 0 && below_word == word);
+        // the last lane of my run: in front of the next lane that starts one (65+: none in the window)
+        uint32_t run_end;
+        {
+          const uint64_t starts_above = (~same_below >> lane) >> 1;
+          uint32_t lo, hi;
+          asm("v_ffbl_b32 %0, %1" : "=v"(lo) : "v"((uint32_t)starts_above));
+          asm("v_ffbl_b32 %0, %1" : "=v"(hi) : "v"((uint32_t)(starts_above >> 32)));
+          const uint32_t r = min(lo, hi | 32u);
+          run_end = r == ~0u ? 127u : (uint32_t)lane + r;
+        }
+        bool trouble = false;
+        if ((uint32_t)lane < kRunSpan) {
+          const uint32_t h_old = table[hpos];
+          const uint32_t ks = hpos & (kFarScratchSlots - 1u);
+          lds_lane_exchange_fence();
+          scr[ks] = (uint16_t)lane; // (the highest lane of a slot stays)
+          lds_lane_exchange_fence();
+          const uint32_t top = scr[ks];
+          lds_lane_exchange_fence();
+          const uint32_t back = (pos - 1u - h_old) & 0xFFFFu;
+          trouble = ((h_old != kNullOffset) & (back < 65535u / S)) || top > run_end;
+        }
+        if (wave_ballot(trouble) == 0) {
+          uint32_t start = 0;
+          uint64_t match_lanes = 0, start_lanes = 0, long_lanes = 0;
+          while (start < kRunSpan) {
+            const uint64_t above = same_below & (~1ull << start) & lanes_below<64>(kRunSpan);
+            if (above == 0)
+              break;
+            const uint32_t g = (uint32_t)__builtin_ctzll(above);
+            const uint64_t not_same = ~(same_below >> g);
+            const uint32_t ml = (uint32_t)__builtin_ctzll(not_same | (1ull << 63));
+            if ((g - start) * S >= 15u || g + ml >= 63u)
+              break; // (length bytes for the literals; a run up to the window's edge may go on)
+            match_lanes |= 1ull << g;
+            start_lanes |= 1ull << start;
+            if (ml * S >= 19u)
+              long_lanes |= 1ull << g; // one length byte (ml * 4 - 19 < 255)
+            start = g + ml;
+          }
+          if (match_lanes != 0) {
+            const uint64_t lits = match_lanes - start_lanes; // lanes start..match-1 of every sequence
+            const bool is_match = ((match_lanes >> lane) & 1ull) != 0, is_lit = ((lits >> lane) & 1ull) != 0;
+            const bool is_long = ((long_lanes >> lane) & 1ull) != 0;
+            const uint32_t lits_below = __builtin_amdgcn_mbcnt_hi((uint32_t)(lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lits, 0u));
+            const uint32_t seqs_below = __builtin_amdgcn_mbcnt_hi((uint32_t)(match_lanes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)match_lanes, 0u));
+            const uint32_t longs_below = __builtin_amdgcn_mbcnt_hi((uint32_t)(long_lanes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)long_lanes, 0u));
+            // (behind the token and the literals below mine of my sequence)
+            const uint32_t at = c + lits_below * S + 3u * seqs_below + longs_below + 1u;
+            if (is_lit)
+              *reinterpret_cast<HC_GLOBAL u32_unaligned*>(out + at) = word;
+            if (is_match) {
+              const uint64_t upto = start_lanes & ((2ull << lane) - 1ull);
+              const uint32_t lit_mine = (uint32_t)lane - (63u - (uint32_t)__builtin_clzll(upto | 1ull));
+              const uint32_t match_bytes = (run_end - (uint32_t)lane + 1u) * S;
+              out[at - 1u - lit_mine * S] = (uint8_t)(((lit_mine * S) << 4) | (is_long ? 15u : match_bytes - 4u));
+              *reinterpret_cast<HC_GLOBAL uint16_t __attribute__((aligned(1)))*>(out + at) = (uint16_t)S; // one element back
+              if (is_long)
+                out[at + 2u] = (uint8_t)(match_bytes - 19u);
+            }
+            far_store_masked(table, hpos, pos & 0xFFFFu, lits, lane);
+            c += (uint32_t)__builtin_popcountll(lits) * S + 3u * (uint32_t)__builtin_popcountll(match_lanes)
+                 + (uint32_t)__builtin_popcountll(long_lanes);
+            const uint32_t moved = start;
+            const int from4 = (int)((((uint32_t)lane + moved) & 63u) * 4u);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(from4, (int)next);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from4, (int)next_hi);
+            wnd = (uint32_t)lane + moved < 64u ? lo : hi;
+            d += moved;
+            token_start = d;
+            cold = 0;
+            next = load_u32_any(in + (size_t)min(d + (uint32_t)lane, last_word) * S);
+            next_hi = load_u32_any(in + (size_t)min(d + 64u + (uint32_t)lane, last_word) * S);
+            runs_rest = 0;
+            runs_fails = 0;
+            if (only_one)
+              break;
+            continue;
+          }
+        }
+      }
+    }
     const uint32_t word = wnd;
     const uint32_t hpos = hash_sum(word) & hmask;
     uint32_t h_old = kNullOffset;

@@ -1399,18 +1399,22 @@ __device__ __forceinline__ bool far_straight(
   bool armed = true;
   uint32_t runs_rest = 0, runs_fails = 0; // (the runs trip below: tried again after twice as many windows when it took nothing)
   while (d + kFarFastMargin <= L) {
-    // ---- Wide, 4-byte elements, runs of values never seen before (a column of
-    // run-length data): every sequence is "one literal element, then the rest of
-    // its run as a match against the lane below", and one trip to the table
-    // settles all of them inside kRunSpan lanes -- provided no lane there has a
-    // table candidate, and every lane that shares its scratch slot (hence
-    // possibly its table slot, or its word) with a higher lane does so only
-    // inside the run of equal words it stands in: then the first lane of a window
-    // with an equal lower lane is the second lane of its first run, the lower
-    // lane is the one right below, and the match is as long as the run.  The
-    // sequences come off the mask of "equal to the lane below" with scalar bit
-    // operations and are written at once as in far_straight_several.
-    if (WIDE && S == 4) {
+    // ---- Wide: runs of values never seen before (run-length data whose values
+    // are of the element's size; `step` = 1 lane).  Every sequence is "the
+    // literals up to the first lane that equals the lane `step` below, then a
+    // match against that lane for as long as that goes on", and one trip to the
+    // table settles all of them
+    // inside kRunSpan lanes -- provided no lane there has a table candidate, and
+    // every lane that shares its scratch slot (hence possibly its table slot, or
+    // its word) with a higher lane does so only with the lanes `step`, 2 x
+    // `step`, ... above it for which that equality goes on without a gap: then the
+    // first lane of a window with an equal lower lane is the first one at least
+    // `step` above its start that equals the lane `step` below, and that lane is
+    // the lowest one with its word.  The sequences come off the mask of "equal
+    // to the lane `step` below" with scalar bit operations and are written at
+    // once as in far_straight_several.  (2- and 4-byte elements: with byte elements
+    // the usual runs are of wider values, which this does not take, and trying costs.)
+    if (WIDE && S > 1) {
       if (runs_rest != 0) {
         --runs_rest;
       } else {
@@ -1420,17 +1424,28 @@ __device__ __forceinline__ bool far_straight(
         const uint32_t word = wnd;
         const uint32_t hpos = hash_sum(word) & hmask;
         const uint32_t pos = d + (uint32_t)lane;
-        const uint32_t below_word = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane - 1u) & 63u) * 4u), (int)word);
-        const uint64_t same_below = wave_ballot(lane > 0 && below_word == word);
-        // the last lane of my run: in front of the next lane that starts one (65+: none in the window)
-        uint32_t run_end;
+        // (equal to the lane right below: with any other distance a lane that shares a
+        // slot with its partners could hide one that does not belong to them)
+        constexpr uint32_t step = 1;
+        uint64_t same_below;
         {
-          const uint64_t starts_above = (~same_below >> lane) >> 1;
+          const uint32_t lower = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane - step) & 63u) * 4u), (int)word);
+          same_below = wave_ballot((uint32_t)lane >= step && lower == word);
+        }
+        // the last lane of the unbroken stretch of "equal to the lane `step` below" that
+        // begins at the lane `step` above mine, or my own lane if that lane is not one
+        // (127: the stretch reaches the window's edge)
+        const uint32_t theirs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane - step) & 63u) * 4u), (int)word);
+        const uint32_t differ = word ^ theirs; // (lanes below `step`: against a wrapped lane, not used)
+        uint32_t stretch_end;
+        {
+          const uint32_t from = (uint32_t)lane + step;
+          const uint64_t breaks_above = from < 64u ? ~same_below >> from : ~0ull;
           uint32_t lo, hi;
-          asm("v_ffbl_b32 %0, %1" : "=v"(lo) : "v"((uint32_t)starts_above));
-          asm("v_ffbl_b32 %0, %1" : "=v"(hi) : "v"((uint32_t)(starts_above >> 32)));
-          const uint32_t r = min(lo, hi | 32u);
-          run_end = r == ~0u ? 127u : (uint32_t)lane + r;
+          asm("v_ffbl_b32 %0, %1" : "=v"(lo) : "v"((uint32_t)breaks_above));
+          asm("v_ffbl_b32 %0, %1" : "=v"(hi) : "v"((uint32_t)(breaks_above >> 32)));
+          const uint32_t r = min(lo, hi | 32u); // lanes from `from` on that are equal to the one `step` below
+          stretch_end = from >= 64u ? (uint32_t)lane : (r == ~0u ? 127u : (r == 0u ? (uint32_t)lane : from + r - 1u));
         }
         bool trouble = false;
         if ((uint32_t)lane < kRunSpan) {
@@ -1442,43 +1457,57 @@ __device__ __forceinline__ bool far_straight(
           const uint32_t top = scr[ks];
           lds_lane_exchange_fence();
           const uint32_t back = (pos - 1u - h_old) & 0xFFFFu;
-          trouble = ((h_old != kNullOffset) & (back < 65535u / S)) || top > run_end;
+          // the highest lane with my word that the stretch explains: mine + a multiple of `step`
+          const uint32_t reach = stretch_end == 127u ? 127u : (uint32_t)lane + (stretch_end - (uint32_t)lane) / step * step;
+          trouble = ((h_old != kNullOffset) & (back < 65535u / S)) || top > reach;
         }
         if (wave_ballot(trouble) == 0) {
           uint32_t start = 0;
-          uint64_t match_lanes = 0, start_lanes = 0, long_lanes = 0;
-          while (start < kRunSpan) {
-            const uint64_t above = same_below & (~1ull << start) & lanes_below<64>(kRunSpan);
+          uint64_t match_lanes = 0, start_lanes = 0;
+          while (start + step < kRunSpan) {
+            const uint64_t above = same_below & (~0ull << (start + step)) & lanes_below<64>(kRunSpan);
             if (above == 0)
               break;
             const uint32_t g = (uint32_t)__builtin_ctzll(above);
-            const uint64_t not_same = ~(same_below >> g);
-            const uint32_t ml = (uint32_t)__builtin_ctzll(not_same | (1ull << 63));
-            if ((g - start) * S >= 15u || g + ml >= 63u)
-              break; // (length bytes for the literals; a run up to the window's edge may go on)
+            const uint32_t n_same = (uint32_t)__builtin_ctzll(~(same_below >> g) | (1ull << 63));
+            if ((g - start) * S >= 15u || g + n_same >= 62u)
+              break; // (length bytes for the literals; a stretch up to the window's edge may go on)
+            // (the partly equal word behind the stretch: at most 3 bytes, less than an element for S = 4)
+            const uint32_t q = g + n_same;
+            const uint32_t ml = (n_same * S + ((uint32_t)__builtin_ctz(read_lane(differ, (int)q) | 0x80000000u) >> 3)) / S;
+            if (ml * S >= 19u + 255u)
+              break;
             match_lanes |= 1ull << g;
             start_lanes |= 1ull << start;
-            if (ml * S >= 19u)
-              long_lanes |= 1ull << g; // one length byte (ml * 4 - 19 < 255)
             start = g + ml;
           }
           if (match_lanes != 0) {
             const uint64_t lits = match_lanes - start_lanes; // lanes start..match-1 of every sequence
             const bool is_match = ((match_lanes >> lane) & 1ull) != 0, is_lit = ((lits >> lane) & 1ull) != 0;
+            // my match, if I am a match lane: as long as the stretch from me on, and the partly equal word behind it
+            const uint32_t my_end = (uint32_t)lane + (uint32_t)__builtin_ctzll(~(same_below >> lane) | (1ull << 63));
+            const uint32_t behind = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((my_end & 63u) * 4u), (int)differ);
+            const uint32_t match_bytes = (((my_end - (uint32_t)lane) * S + ((uint32_t)__builtin_ctz(behind | 0x80000000u) >> 3)) / S) * S;
+            const uint64_t long_lanes = wave_ballot(is_match && match_bytes >= 19u); // one length byte
             const bool is_long = ((long_lanes >> lane) & 1ull) != 0;
             const uint32_t lits_below = __builtin_amdgcn_mbcnt_hi((uint32_t)(lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lits, 0u));
             const uint32_t seqs_below = __builtin_amdgcn_mbcnt_hi((uint32_t)(match_lanes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)match_lanes, 0u));
             const uint32_t longs_below = __builtin_amdgcn_mbcnt_hi((uint32_t)(long_lanes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)long_lanes, 0u));
             // (behind the token and the literals below mine of my sequence)
             const uint32_t at = c + lits_below * S + 3u * seqs_below + longs_below + 1u;
-            if (is_lit)
-              *reinterpret_cast<HC_GLOBAL u32_unaligned*>(out + at) = word;
+            if (is_lit) {
+              if (S == 1)
+                out[at] = (uint8_t)word;
+              else if (S == 2)
+                *reinterpret_cast<HC_GLOBAL uint16_t __attribute__((aligned(1)))*>(out + at) = (uint16_t)word;
+              else
+                *reinterpret_cast<HC_GLOBAL u32_unaligned*>(out + at) = word;
+            }
             if (is_match) {
               const uint64_t upto = start_lanes & ((2ull << lane) - 1ull);
               const uint32_t lit_mine = (uint32_t)lane - (63u - (uint32_t)__builtin_clzll(upto | 1ull));
-              const uint32_t match_bytes = (run_end - (uint32_t)lane + 1u) * S;
               out[at - 1u - lit_mine * S] = (uint8_t)(((lit_mine * S) << 4) | (is_long ? 15u : match_bytes - 4u));
-              *reinterpret_cast<HC_GLOBAL uint16_t __attribute__((aligned(1)))*>(out + at) = (uint16_t)S; // one element back
+              *reinterpret_cast<HC_GLOBAL uint16_t __attribute__((aligned(1)))*>(out + at) = (uint16_t)(step * S);
               if (is_long)
                 out[at + 2u] = (uint8_t)(match_bytes - 19u);
             }

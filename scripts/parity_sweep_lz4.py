@@ -20,8 +20,9 @@ for es, dtype in ((1, 0), (2, 3), (4, 4)):
             base.append(datagen.random_runs_int32(3200 + k, size // 4 + 1).tobytes()[: size - 2 * k])
             base.append(datagen.vocabulary_text(3300 + k, size, 64, 8))
             base.append(datagen.periodic_bytes(3400 + k, size, 3 + k, 40))
+            base.append(datagen.runs_of_elements(3500 + k, size, es, 4 + 3 * k))
         base = [c[: len(c) // es * es] for c in base]
-        chunks = base * 24  # 1200 chunks: more than the LDS shape holds in flight
+        chunks = base * 20  # 1200 chunks: more than the LDS shape holds in flight
         cap = max(len(c) for c in chunks)
         want = [O.lz4_compress(c, es, cap) for c in base]
         src = hc.batch.from_host_chunks(chunks, "cuda:0")

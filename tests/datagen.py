@@ -260,3 +260,14 @@ def trip_corner_chunks():
         out.append(tpch_lineitem_text(1250 + i, 65536 - 7 * i))
     assert len(out) == 64
     return out
+
+
+def runs_of_elements(seed: int, n_bytes: int, elem_size: int, longest: int = 16) -> bytes:
+    """Run-length data whose values are of the element's size: value = run index (wrapping in
+    the element), run lengths ~ U[1, longest] elements."""
+    n = n_bytes // elem_size + longest
+    r = splitmix64(seed, n)
+    lengths = (r % np.uint64(longest)).astype(np.int64) + 1
+    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[elem_size]
+    values = np.arange(len(lengths), dtype=np.uint64).astype(dt)
+    return np.repeat(values, lengths)[: n_bytes // elem_size].tobytes()

@@ -197,6 +197,38 @@ def test_most_repetitive_batches_take_the_widest_span(hc, oracle, reflib, cuda, 
     assert dec.to_host_chunks() == chunks
 
 
+@pytest.mark.parametrize("tname,dtype,es", TYPES)
+def test_runs_of_element_sized_values(hc, oracle, reflib, cuda, tname, dtype, es):
+    """Run-length data whose values are of the element's size (the wide form's
+    runs trip for 2- and 4-byte elements: all sequences of 48 lanes from one trip
+    to the table), run lengths up to 2 .. 60 elements, ragged chunk lengths: every
+    chunk against the oracle and the reference build, then the round trip."""
+    import torch
+    base = []
+    for k, longest in enumerate((2, 3, 4, 6, 8, 12, 16, 24, 32, 40, 60, 5)):
+        for j in range(4):
+            base.append(datagen.runs_of_elements(800 + 10 * k + j, 65536 - 4 * (k + 7 * j), es, longest))
+    assert len(base) == 48
+    chunks = base * 32
+    want = [oracle.lz4_compress(c, es, 65536) for c in base]
+    src = hc.batch.from_host_chunks(chunks, "cuda:0")
+    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
+    mine = codec.compress(src, 65536)
+    torch.cuda.synchronize()
+    got = mine.to_host_chunks()
+    for i in range(len(chunks)):
+        assert got[i] == want[i % len(base)], f"chunk {i} {tname}: kernel != oracle"
+    if reflib is not None:
+        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=reflib).compress(src, 65536)
+        torch.cuda.synchronize()
+        refgot = ref.to_host_chunks()
+        for i in range(len(base)):
+            assert refgot[i] == want[i], f"chunk {i} {tname}: oracle != reference"
+    dec, actual, statuses = codec.decompress(mine, 65536)
+    assert statuses.cpu().tolist() == [0] * len(chunks)
+    assert dec.to_host_chunks() == chunks
+
+
 def test_small_tables_many_waves_per_group(hc, oracle, cuda):
     """max_chunk below 16 KiB: smaller hash tables, up to 16 waves (= chunks
     in flight) per workgroup, batch sizes that do not fill the last group."""

@@ -33,7 +33,7 @@ struct Lz4CompressShape
 Lz4CompressShape lz4_compress_shape_mix(uint32_t ht_size, size_t batch);
 
 enum class Lz4Mode { Auto, Mix, Far, FarWide };
-// HIPCOMP_LZ4_SHAPE = auto | mix | far | farw (read once; default auto).  A
+// HIPCOMP_LZ4_SHAPE = auto | mix | far | farw (read at every call; default auto).  A
 // measurement / test knob: the compressed bytes do not depend on it.
 Lz4Mode lz4_mode_from_environment();
 

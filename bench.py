@@ -557,9 +557,6 @@ def main():
         if not args.no_cpu:
             crow["cpu_baseline"] = cpu_codec_baseline("Cascaded", cols[: 8192 * CHUNK].cpu().numpy())
         rows.append(crow)
-        for cb in (8192, 16384):   # opts.chunk_size honoured; 4096 above is the reference's
-            rows.append(measure_row(hc, lib, "Cascaded", hc.CascadedOpts(cb, hc.hipcompType.UINT, 2, 1, 1), cols,
-                                    {"codec": "Cascaded", "config": f"same columns, opts {{{cb}, UINT, 2, 1, 1}}"}))
         del cols
         res["extra_keys"] = rows
     if rank == 0:

@@ -12,6 +12,9 @@
 #include "cascaded_launch.hpp"
 #include "host_common.hpp"
 
+#include <cstdlib>
+#include <cstring>
+
 using namespace hcamd;
 
 namespace {
@@ -40,6 +43,14 @@ bool elem_size_of(hipcompType_t t, int& s)
   }
 }
 
+} // namespace
+
+namespace {
+bool chunk_size_extension()
+{
+  const char* e = std::getenv("HIPCOMP_CASCADED_CHUNK_SIZE");
+  return e && std::strcmp(e, "honour") == 0;
+}
 } // namespace
 
 extern "C" {
@@ -93,9 +104,14 @@ hipcompStatus_t hipcompBatchedCascadedCompressAsync(
       device_compressed_bytes, batch_size, (int)format_opts.type, s, R, D,
       format_opts.use_bp ? 1 : 0,
       // chunk_size: the reference ignores the field (cascaded.h:93-100) and cuts
-      // partitions into 4096-byte sub-chunks; 8192 and 16384 are honoured here,
-      // every other value means the reference's
-      (format_opts.chunk_size == 8192 || format_opts.chunk_size == 16384) ? (uint32_t)format_opts.chunk_size : 4096u,
+      // partitions into 4096-byte sub-chunks, and so does this by default -- a
+      // caller of the reference that passes 8192 keeps getting streams the
+      // reference reads.  With HIPCOMP_CASCADED_CHUNK_SIZE=honour in the
+      // environment 8192 and 16384 are honoured (an extension: such streams need
+      // this library's decoder); every other value means 4096.
+      chunk_size_extension() && (format_opts.chunk_size == 8192 || format_opts.chunk_size == 16384)
+          ? (uint32_t)format_opts.chunk_size
+          : 4096u,
       stream);
   std::string why;
   if (!launch_ok("cascaded compression kernel", why))
@@ -131,11 +147,13 @@ hipcompStatus_t hipcompBatchedCascadedDecompressAsync(
   HCAMD_REQUIRE_NOT_NULL(fn, device_statuses);
   if (batch_size == 0)
     return hipcompSuccess;
-  cascaded_launch_decompress(
+  const hipError_t e = cascaded_launch_decompress(
       reinterpret_cast<const uint8_t* const*>(device_compressed_ptrs),
       device_compressed_bytes, device_uncompressed_bytes, batch_size,
       reinterpret_cast<uint8_t* const*>(device_uncompressed_ptrs),
       device_actual_uncompressed_bytes, device_statuses, stream);
+  if (e != hipSuccess)
+    return fail(fn, std::string("cascaded decompress launch: ") + hipGetErrorString(e));
   std::string why;
   if (!launch_ok("cascaded decompression kernel", why))
     return fail(fn, why);

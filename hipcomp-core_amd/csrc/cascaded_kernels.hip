@@ -908,16 +908,17 @@ CompressKernel compress_kernel_of(uint32_t cb, uint32_t& lds)
 }
 
 template <int S, int CB>
-void launch_decompress(
+hipError_t launch_decompress(
     const uint8_t* const* comp_ptrs, const size_t* comp_bytes, const size_t* out_caps, size_t batch,
     uint8_t* const* out_ptrs, size_t* actual_bytes, hipcompStatus_t* statuses, hipStream_t stream)
 {
   DecompressKernel k = cascaded_decompress_kernel<S, CB>;
   constexpr uint32_t lds = dec_lds_bytes<S, CB>();
   if (lds > 64 * 1024) { // has to be asked for (idempotent, cheap)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-        != hipSuccess)
-      return;
+    const hipError_t e
+        = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess)
+      return e;
   }
   // as many one-wave workgroups as the chip holds with this much LDS each (handed out in 1280-byte granules)
   uint32_t per_cu = (160u * 1024u) / ((lds + 1279u) / 1280u * 1280u);
@@ -926,6 +927,7 @@ void launch_decompress(
   const size_t resident = (size_t)num_cus_of_current_device() * per_cu;
   k<<<dim3((unsigned)(batch < resident ? batch : resident)), dim3(kWave), lds, stream>>>(
       comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
+  return hipSuccess;
 }
 
 } // namespace
@@ -949,16 +951,25 @@ void cascaded_launch_compress(
 // One launch per element width and sub-chunk size (the reference: one per
 // width); a launch leaves the partitions of the others alone.  The common
 // ones first.
-void cascaded_launch_decompress(
+hipError_t cascaded_launch_decompress(
     const uint8_t* const* comp_ptrs, const size_t* comp_bytes,
     const size_t* out_caps, size_t batch, uint8_t* const* out_ptrs,
     size_t* actual_bytes, hipcompStatus_t* statuses, hipStream_t stream)
 {
-#define HC_DEC(S, CB) launch_decompress<S, CB>(comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses, stream)
-  HC_DEC(4, 4096); HC_DEC(8, 4096); HC_DEC(2, 4096); HC_DEC(1, 4096);
-  HC_DEC(4, 8192); HC_DEC(8, 8192); HC_DEC(2, 8192); HC_DEC(1, 8192);
-  HC_DEC(4, 16384); HC_DEC(8, 16384); HC_DEC(2, 16384); HC_DEC(1, 16384);
+  // (every launch is set up before the first one runs anything the caller could see half-done:
+  // the LDS limits are raised first, in the order of the launches)
+#define HC_DEC(S, CB)                                                                                              \
+  {                                                                                                                \
+    const hipError_t e = launch_decompress<S, CB>(comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, \
+                                                  statuses, stream);                                               \
+    if (e != hipSuccess)                                                                                           \
+      return e;                                                                                                    \
+  }
+  HC_DEC(4, 4096) HC_DEC(8, 4096) HC_DEC(2, 4096) HC_DEC(1, 4096)
+  HC_DEC(4, 8192) HC_DEC(8, 8192) HC_DEC(2, 8192) HC_DEC(1, 8192)
+  HC_DEC(4, 16384) HC_DEC(8, 16384) HC_DEC(2, 16384) HC_DEC(1, 16384)
 #undef HC_DEC
+  return hipSuccess;
 }
 
 void cascaded_launch_get_sizes(

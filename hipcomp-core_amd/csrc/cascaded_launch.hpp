@@ -14,7 +14,8 @@ void cascaded_launch_compress(
     uint8_t* const* out_ptrs, size_t* out_bytes, size_t batch, int type_tag,
     int elem_size, int num_rles, int num_deltas, int use_bp, uint32_t chunk_bytes, hipStream_t stream);
 
-void cascaded_launch_decompress(
+// an error: a launch could not be set up (nothing was decoded by it; the caller fails the call)
+hipError_t cascaded_launch_decompress(
     const uint8_t* const* comp_ptrs, const size_t* comp_bytes,
     const size_t* out_caps, size_t batch, uint8_t* const* out_ptrs,
     size_t* actual_bytes, hipcompStatus_t* statuses, hipStream_t stream);

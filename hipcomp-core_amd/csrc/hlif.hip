@@ -174,20 +174,37 @@ __global__ __launch_bounds__(kBlock) void slab_gather_kernel(
 }
 
 // ---- decompression ------------------------------------------------------------------------
+// The header is the container's own word about itself and may be corrupt or hostile: the
+// chunk list of a slab is made only if it agrees with what the manager and the caller's
+// configuration say (format, chunk size, chunk count, size of the output, where the data
+// starts) -- otherwise every chunk of the slab gets an empty output slice and a one-byte
+// stream, fails, and the verdict kernel reports hipcompErrorCannotDecompress.  Either way no
+// output slice reaches past decomp_bytes.
 __global__ void slab_streams_kernel(
     const uint8_t* container, uint64_t offsets_at, uint8_t* decomp, uint64_t decomp_bytes,
-    uint64_t chunk_bytes, uint64_t first, uint32_t count, const uint8_t** comp_ptrs, uint8_t** out_ptrs, size_t* caps)
+    uint64_t chunk_bytes, uint64_t first, uint32_t count, uint64_t num_chunks, uint32_t format, uint64_t data_at,
+    const uint8_t** comp_ptrs, uint8_t** out_ptrs, size_t* caps, hipcompStatus_t* status)
 {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= count)
     return;
-  // the chunk data starts where the header says (a reference-written container's too)
-  const uint64_t data_at = reinterpret_cast<const CommonHeader*>(container)->comp_data_offset;
+  const CommonHeader* h = reinterpret_cast<const CommonHeader*>(container);
+  const bool header_ok = h->format == format && h->uncomp_chunk_size == chunk_bytes
+                         && h->num_chunks == num_chunks && h->decomp_data_size == decomp_bytes
+                         && h->comp_data_offset == data_at
+                         && num_chunks == (decomp_bytes + chunk_bytes - 1) / chunk_bytes;
   const uint64_t off = reinterpret_cast<const uint64_t*>(container + offsets_at)[first + i];
   const uint64_t at = (first + i) * chunk_bytes;
+  if (!header_ok) {
+    comp_ptrs[i] = container;
+    out_ptrs[i] = decomp;
+    caps[i] = 0;
+    *status = hipcompErrorCannotDecompress;
+    return;
+  }
   comp_ptrs[i] = container + data_at + off;
   out_ptrs[i] = decomp + at;
-  caps[i] = (size_t)(decomp_bytes - at < chunk_bytes ? decomp_bytes - at : chunk_bytes);
+  caps[i] = at >= decomp_bytes ? 0 : (size_t)(decomp_bytes - at < chunk_bytes ? decomp_bytes - at : chunk_bytes);
 }
 
 // a chunk that failed, or did not fill its slice, fails the whole buffer
@@ -346,10 +363,30 @@ struct Core
     return *header_host;
   }
 
+  // A header that contradicts this manager (another format or chunk size, a chunk count that
+  // is not that of its own sizes, data that does not start behind its own tables) configures
+  // nothing: status hipcompErrorCannotDecompress, zero bytes, zero chunks -- decompress() then
+  // launches nothing.
+  bool header_fits(const CommonHeader& h) const
+  {
+    if (h.format != format || h.uncomp_chunk_size != chunk_bytes || chunk_bytes == 0)
+      return false;
+    const uint64_t want_chunks = (h.decomp_data_size + chunk_bytes - 1) / chunk_bytes;
+    if (h.num_chunks != want_chunks || want_chunks > 0xFFFFFFFFull)
+      return false;
+    return h.comp_data_offset == layout((size_t)h.num_chunks).data;
+  }
+
   hipcomp::DecompressionConfig configure_decompression(const uint8_t* comp_buffer)
   {
     hipcomp::DecompressionConfig d;
     const CommonHeader& h = read_header(comp_buffer);
+    if (!header_fits(h)) {
+      *d.get_status() = hipcompErrorCannotDecompress;
+      d.decomp_data_size = 0;
+      d.num_chunks = 0;
+      return d;
+    }
     d.decomp_data_size = (size_t)h.decomp_data_size;
     d.num_chunks = (uint32_t)h.num_chunks;
     return d;
@@ -365,12 +402,15 @@ struct Core
     uint8_t** out_ptrs = reinterpret_cast<uint8_t**>(s + (size_t)slab * 16);
     size_t* actual = reinterpret_cast<size_t*>(s + (size_t)slab * 24);
     hipcompStatus_t* statuses = reinterpret_cast<hipcompStatus_t*>(s + (size_t)slab * 40);
+    // (a configuration refused by configure_decompression: nothing to do, its status stands)
+    if (n == 0 && cfg.decomp_data_size == 0 && *cfg.get_status() == hipcompErrorCannotDecompress)
+      return;
     set_status_kernel<<<1, 1, 0, stream>>>(cfg.get_status(), hipcompSuccess);
     for (size_t first = 0; first < n; first += slab) {
       const uint32_t count = (uint32_t)(n - first < slab ? n - first : slab);
       slab_streams_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, stream>>>(
-          comp_buffer, lay.offsets, decomp_buffer, cfg.decomp_data_size, chunk_bytes, first, count, comp_ptrs, out_ptrs,
-          caps);
+          comp_buffer, lay.offsets, decomp_buffer, cfg.decomp_data_size, chunk_bytes, first, count, n, format, lay.data,
+          comp_ptrs, out_ptrs, caps, cfg.get_status());
       const size_t* sizes = reinterpret_cast<const size_t*>(comp_buffer + lay.sizes) + first;
       switch (codec) {
       case LZ4:

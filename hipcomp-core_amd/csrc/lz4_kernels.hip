@@ -58,6 +58,7 @@
 #include "wave_utils.hpp"
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -132,6 +133,17 @@ FarKernel far_kernel_for(int elem_size, bool wide)
                                                                               : lz4_compress_kernel_far<4, false>;
 }
 
+typedef void (*BothKernel)(const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint16_t*,
+                           uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*);
+BothKernel both_kernel_for(int elem_size, bool wide)
+{
+  if (wide)
+    return elem_size == 1 ? lz4_compress_kernel_both<1, true> : elem_size == 2 ? lz4_compress_kernel_both<2, true>
+                                                                                : lz4_compress_kernel_both<4, true>;
+  return elem_size == 1 ? lz4_compress_kernel_both<1, false> : elem_size == 2 ? lz4_compress_kernel_both<2, false>
+                                                                               : lz4_compress_kernel_both<4, false>;
+}
+
 // more than 64 KiB of dynamic LDS has to be asked for, once per kernel and device
 hipError_t raise_dynamic_lds_limit()
 {
@@ -147,6 +159,9 @@ hipError_t raise_dynamic_lds_limit()
   for (int es = 1; es <= 4 && r == hipSuccess; es *= 2) {
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(mix_kernel_for(es)),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int wide = 0; wide < 2 && r == hipSuccess; ++wide)
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(both_kernel_for(es, wide != 0)),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   g_lds_raised[dev].store(r == hipSuccess ? 1 : -(int)r, std::memory_order_release);
   return r;
@@ -225,6 +240,30 @@ Lz4Mode lz4_mode_from_environment()
   return Lz4Mode::Auto;
 }
 
+namespace {
+// Measurement knob HIPCOMP_LZ4_BOTH="near,far,slots": the far shapes run as the "both"
+// kernel with that many LDS-table waves and device-table waves per workgroup and that
+// many scratch slots per wave (a power of two).
+struct BothGeometry
+{
+  uint32_t near = 0, far = 0, slots = 0;
+  bool on() const { return near + far > 0; }
+};
+BothGeometry both_from_environment()
+{
+  BothGeometry g;
+  const char* e = std::getenv("HIPCOMP_LZ4_BOTH");
+  unsigned a = 0, b = 0, c = 0;
+  if (e && std::sscanf(e, "%u,%u,%u", &a, &b, &c) == 3 && a + b >= 1 && a + b <= (unsigned)kBothMaxWavesPerGroup
+      && c >= 64 && c <= 4096 && (c & (c - 1)) == 0) {
+    g.near = a;
+    g.far = b;
+    g.slots = c;
+  }
+  return g;
+}
+} // namespace
+
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
@@ -283,11 +322,31 @@ hipError_t lz4_launch_compress(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
         (uint32_t)batch, ticket, chunks_per_ticket(mix), chosen);
   }
+  const BothGeometry both = both_from_environment();
+  Lz4CompressShape bs = {};
+  if (both.on()) {
+    bs.tagged = both.near; // (waves with their table in LDS)
+    bs.plain = both.far;
+    bs.lds_bytes = both.near * (2u * (ht_size < 8 ? 8u : ht_size) + 2u * both.slots) + both.far * 2u * both.slots;
+    if (bs.lds_bytes > kLdsPerCu)
+      return hipErrorInvalidValue;
+    set_groups(bs, batch);
+    if (both.far > 0 && (size_t)bs.groups * both.far > far_capacity)
+      bs.groups = (uint32_t)(far_capacity / both.far);
+    if (bs.groups == 0)
+      return hipErrorInvalidValue;
+  }
   for (int wide = 0; wide < 2; ++wide)
-    if (mode == Lz4Mode::Auto || mode == (wide ? Lz4Mode::FarWide : Lz4Mode::Far))
-      far_kernel_for(elem_size, wide != 0)<<<dim3(far.groups), dim3(far.waves() * kWave), far.lds_bytes, stream>>>(
-          in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, (uint32_t)batch, ticket,
-          chunks_per_ticket(far), chosen);
+    if (mode == Lz4Mode::Auto || mode == (wide ? Lz4Mode::FarWide : Lz4Mode::Far)) {
+      if (both.on())
+        both_kernel_for(elem_size, wide != 0)<<<dim3(bs.groups), dim3(bs.waves() * kWave), bs.lds_bytes, stream>>>(
+            in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, both.near, both.slots, (uint32_t)batch, ticket,
+            chunks_per_ticket(bs), chosen);
+      else
+        far_kernel_for(elem_size, wide != 0)<<<dim3(far.groups), dim3(far.waves() * kWave), far.lds_bytes, stream>>>(
+            in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, (uint32_t)batch, ticket,
+            chunks_per_ticket(far), chosen);
+    }
   return hipSuccess;
 }
 

@@ -18,7 +18,13 @@ extern "C" {
 #endif
 
 /* reference cascaded.h:90-125.  chunk_size is carried but, as in the
- * reference, the internal sub-chunk is fixed at 4096 bytes. */
+ * reference, the internal sub-chunk is fixed at 4096 bytes whatever it says,
+ * and the streams are the reference's.  (An extension of this library, off by
+ * default: with HIPCOMP_CASCADED_CHUNK_SIZE=honour in the environment the
+ * values 8192 and 16384 are honoured; such streams carry the size in the high
+ * nibble of header byte 2 and are NOT readable by the reference -- its decoder
+ * takes the byte for use_bp and walks 4096-byte sub-chunks.  This library's
+ * decoder reads all three sizes with or without the variable.) */
 typedef struct
 {
   size_t chunk_size;

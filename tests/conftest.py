@@ -35,6 +35,31 @@ def reflib(hc):
     return hc.HipcompLibrary(O.REF_LIB_PATH)
 
 
+LZ4_SHAPES = ("auto", "mix", "far", "farw")
+
+
+@pytest.fixture(params=LZ4_SHAPES)
+def lz4_shape(request, monkeypatch):
+    """Every launch shape of the LZ4 encoder in turn (HIPCOMP_LZ4_SHAPE is read at
+    every call): "auto" lets the sampling kernel pick, the others force one --
+    also on data it would never be picked for (the far shapes on chunks without
+    a match, the LDS shape and the wide form on text).  The compressed bytes
+    must not depend on it."""
+    monkeypatch.setenv("HIPCOMP_LZ4_SHAPE", request.param)
+    return request.param
+
+
+def compare_with_reference(reflib, what, check):
+    """Runs `check(reflib)` -- the asserts of a test that compare with the
+    reference's own build -- or, when oracle/_ref is absent, reports the test
+    as SKIPPED with the reason instead of passing silently.  Call it last: the
+    asserts against the oracle have passed by then."""
+    if reflib is None:
+        pytest.skip(f"oracle/_ref/libhipcomp_ref.so absent: {what} not compared with the reference build "
+                    "(the comparisons with the oracle passed)")
+    check(reflib)
+
+
 @pytest.fixture(scope="session")
 def cuda():
     import torch

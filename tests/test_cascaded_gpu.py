@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import datagen
+from conftest import compare_with_reference
 from test_cascaded_oracle_cpu import NP, _predefined, _sorted_column, no_progress_streams
 
 pytestmark = pytest.mark.gpu
@@ -34,6 +35,7 @@ def _inputs(t, oracle):
 def test_compress_parity_and_roundtrip(hc, oracle, reflib, cuda, opts):
     import torch
     R, D, bp = opts
+    todo = []   # what the reference build is compared on, after the oracle asserts
     for t in range(8):
         chunks = _inputs(t, oracle)
         src = hc.batch.from_host_chunks(chunks, "cuda:0")
@@ -42,18 +44,9 @@ def test_compress_parity_and_roundtrip(hc, oracle, reflib, cuda, opts):
         mine = codec.compress(src)
         torch.cuda.synchronize()
         got = mine.to_host_chunks()
-        refgot = None
-        # the reference is undefined (endless loop) when a delta layer meets 0 elements
-        # (CascadedKernels.hiph:323) and cannot decode D > R >= 1: compare it for D <= 1 only
-        if reflib is not None and D <= 1:
-            r = hc.batch.Codec("Cascaded", copts, lib=reflib).compress(src)
-            torch.cuda.synchronize()
-            refgot = r.to_host_chunks()
+        wants = [oracle.cascaded_compress(c, t, R, D, bp) for c in chunks]
         for i, c in enumerate(chunks):
-            want, mask = oracle.cascaded_compress(c, t, R, D, bp)
-            assert got[i] == want, f"type {t} opts {opts} input {i}: kernel != oracle"
-            if refgot is not None:
-                assert oracle.masked_equal(refgot[i], want, mask), f"type {t} opts {opts} input {i}: oracle != reference"
+            assert got[i] == wants[i][0], f"type {t} opts {opts} input {i}: kernel != oracle"
         s = oracle.CASCADED_TYPE_SIZE[t]
         expect = [c[: len(c) // s * s] for c in chunks]
         assert codec.get_decompress_size(mine).cpu().tolist() == [len(e) for e in expect]
@@ -65,7 +58,16 @@ def test_compress_parity_and_roundtrip(hc, oracle, reflib, cuda, opts):
             else:
                 assert st[i] == 0 and ac[i] == len(e), (t, opts, i)
                 assert dec.chunk_bytes(i, ac[i]) == e
-        if refgot is not None and reflib is not None:
+        todo.append((t, chunks, src, copts, mine, wants, expect))
+
+    def check(reflib):
+        for t, chunks, src, copts, mine, wants, expect in todo:
+            r = hc.batch.Codec("Cascaded", copts, lib=reflib).compress(src)
+            torch.cuda.synchronize()
+            refgot = r.to_host_chunks()
+            for i in range(len(chunks)):
+                want, mask = wants[i]
+                assert oracle.masked_equal(refgot[i], want, mask), f"type {t} opts {opts} input {i}: oracle != reference"
             # the reference decodes our streams (it dispatches on partition 0's type: same type everywhere here)
             rdec, ractual, rstat = hc.batch.Codec("Cascaded", copts, lib=reflib).decompress(mine, 65536 * 2)
             rs = rstat.cpu().tolist()
@@ -73,6 +75,10 @@ def test_compress_parity_and_roundtrip(hc, oracle, reflib, cuda, opts):
                 if len(chunks[i]):
                     assert rs[i] == 0, (t, opts, i)
                     assert rdec.chunk_bytes(i, len(e)) == e
+    # the reference is undefined (endless loop) when a delta layer meets 0 elements
+    # (CascadedKernels.hiph:323) and cannot decode D > R >= 1: compared for D <= 1 only
+    if D <= 1:
+        compare_with_reference(reflib, f"Cascaded opts {opts}", check)
 
 
 def test_mixed_types_in_one_batch_decode_per_partition(hc, oracle, cuda):
@@ -129,6 +135,7 @@ def test_large_partitions(hc, oracle, reflib, cuda):
     import torch
     chunks = [_sorted_column(3, 262144).tobytes(), _sorted_column(4, 100003).astype(np.uint16).tobytes() + b"\x07",
               np.repeat(np.arange(5000, dtype=np.int64), 37).tobytes()]
+    todo = []
     for t, c in zip((5, 3, 6), chunks):
         src = hc.batch.from_host_chunks([c], "cuda:0")
         copts = hc.CascadedOpts(4096, t, 2, 1, 1)
@@ -137,22 +144,45 @@ def test_large_partitions(hc, oracle, reflib, cuda):
         torch.cuda.synchronize()
         want, mask = oracle.cascaded_compress(c, t, 2, 1, 1)
         assert mine.to_host_chunks()[0] == want
-        if reflib is not None:
-            r = hc.batch.Codec("Cascaded", copts, lib=reflib).compress(src)
-            torch.cuda.synchronize()
-            assert oracle.masked_equal(r.to_host_chunks()[0], want, mask)
         s = oracle.CASCADED_TYPE_SIZE[t]
         dec, actual, statuses = codec.decompress(mine, len(c) + 16)
         assert statuses.cpu().tolist() == [0]
         assert dec.to_host_chunks()[0] == c[: len(c) // s * s]
+        todo.append((src, copts, want, mask))
+
+    def check(reflib):
+        for src, copts, want, mask in todo:
+            r = hc.batch.Codec("Cascaded", copts, lib=reflib).compress(src)
+            torch.cuda.synchronize()
+            assert oracle.masked_equal(r.to_host_chunks()[0], want, mask)
+    compare_with_reference(reflib, "Cascaded large partitions", check)
+
+
+def test_chunk_size_is_ignored_by_default_as_in_the_reference(hc, oracle, reflib, cuda, monkeypatch):
+    """The reference ignores opts.chunk_size (cascaded.h:93-100) and always writes 4096-byte
+    sub-chunks; so does the product unless the extension is switched on: a caller that passes
+    8192 gets the reference's bytes."""
+    monkeypatch.delenv("HIPCOMP_CASCADED_CHUNK_SIZE", raising=False)
+    data = _sorted_column(2, 16384).tobytes()
+    src = hc.batch.from_host_chunks([data], "cuda:0")
+    want, mask = oracle.cascaded_compress(data, 5, 2, 1, 1)
+    for cb in (4096, 8192, 16384, 512):
+        assert hc.batch.Codec("Cascaded", hc.CascadedOpts(cb, 5, 2, 1, 1)).compress(src).to_host_chunks()[0] == want
+
+    def check(reflib):
+        for cb in (4096, 8192, 16384):
+            got = hc.batch.Codec("Cascaded", hc.CascadedOpts(cb, 5, 2, 1, 1), lib=reflib).compress(src).to_host_chunks()[0]
+            assert oracle.masked_equal(got, want, mask)
+    compare_with_reference(reflib, "chunk_size ignored", check)
 
 
 @pytest.mark.parametrize("cb", [8192, 16384])
-def test_chunk_size_option_is_honoured(hc, oracle, cuda, cb):
-    """hipcompBatchedCascadedOpts_t.chunk_size 8192 / 16384: kernel == oracle
-    byte for byte, round trips, and partitions of all three sub-chunk sizes and several types
-    decode side by side in one batch."""
+def test_chunk_size_option_is_honoured(hc, oracle, cuda, monkeypatch, cb):
+    """The extension (HIPCOMP_CASCADED_CHUNK_SIZE=honour): chunk_size 8192 / 16384,
+    kernel == oracle byte for byte, round trips, and partitions of all three sub-chunk sizes and
+    several types decode side by side in one batch (the decoder needs no switch)."""
     import torch
+    monkeypatch.setenv("HIPCOMP_CASCADED_CHUNK_SIZE", "honour")
     for R, D, bp in ((2, 1, 1), (1, 0, 0), (0, 2, 1)):
         mixed, expect = [], []
         for t in range(8):

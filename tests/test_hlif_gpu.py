@@ -122,6 +122,53 @@ def test_container_layout_chunks_and_round_trip(hc, oracle, cuda, chunk, dtype, 
     m.close()
 
 
+def test_hostile_container_headers_are_refused(hc, cuda):
+    """The container header is the buffer's own word about itself: one that contradicts the
+    manager (chunk count that is not ceil(size / chunk), another chunk size or format, data that
+    does not start behind its own tables, a larger output than the chunks can fill) must end in
+    hipcompErrorCannotDecompress with nothing written past the caller's output -- not in slices
+    that wrap around (caps = decomp_bytes - at underflowed)."""
+    import torch
+    L = _lib(hc)
+    chunk = 4096
+    m = Manager(L, chunk, 0)
+    data = datagen.text_like(31, 10 * chunk - 77)
+    cont, nc = m.compress(data, cuda)
+    assert nc == 10
+    st, back = m.decompress(cont, cuda)
+    assert st == 0 and back == data
+
+    def patched(fmt, at, value):
+        b = bytearray(cont)
+        struct.pack_into(fmt, b, at, value)
+        return bytes(b)
+    hostile = {
+        "num_chunks too large": patched("<Q", 24, 1000),
+        "num_chunks too small": patched("<Q", 24, 3),
+        "decomp size smaller than the chunks": patched("<Q", 16, 2 * chunk),
+        "decomp size larger than the chunks": patched("<Q", 16, 50 * chunk),
+        "another chunk size": patched("<Q", 48, 2 * chunk),
+        "another format": patched("<B", 6, 1),
+        "data offset moved": patched("<I", 56, 72 + 24 * 10 + 4096),
+    }
+    for what, bad in hostile.items():
+        src = torch.from_numpy(np.frombuffer(bad, dtype=np.uint8).copy()).to(cuda)
+        # an output buffer of the TRUE size with a guard zone behind it
+        dst = torch.full((len(data) + (1 << 20),), 0x5A, dtype=torch.uint8, device=cuda)
+        n, k = c_size_t(123), c_size_t(456)
+        assert L.hipcompHlifGetDecompressedSize(m.h, c_void_p(src.data_ptr()), ctypes.byref(n), ctypes.byref(k)) == 0
+        assert (n.value, k.value) == (0, 0), what
+        assert L.hipcompHlifDecompress(m.h, c_void_p(src.data_ptr()), c_void_p(dst.data_ptr())) == 0
+        st = c_int(-1)
+        assert L.hipcompHlifGetLastStatus(m.h, ctypes.byref(st)) == 0
+        assert st.value == 12, what
+        assert bool((dst == 0x5A).all().item()), what + ": wrote to the output"
+    # the manager still works afterwards
+    st, back = m.decompress(cont, cuda)
+    assert st == 0 and back == data
+    m.close()
+
+
 def test_many_chunks_take_several_slabs(hc, cuda):
     L = _lib(hc)
     m = Manager(L, 1024, 0)                                   # slab = 8192 chunks: 20000 chunks = 3 passes

@@ -1,90 +1,114 @@
 """LZ4 parity on the GPU, through the C ABI: compressed bytes vs the CPU
-oracle and vs the reference's own build (oracle/_ref, when present), round
-trips, the reference harness's batches and its error-path checks
-(reference tests/test_batch_c_api.h:225-790)."""
+oracle and vs the reference's own build (oracle/_ref; when it is absent the
+test is reported as skipped, with the reason, after its oracle asserts have
+passed), round trips, the reference harness's batches and its error-path checks
+(reference tests/test_batch_c_api.h:225-790).  The encoder tests run once per
+launch shape (conftest.lz4_shape): the sampler's choice and every forced shape,
+also on data the shape would never be chosen for."""
 import ctypes
+import hashlib
 import os
 
 import numpy as np
 import pytest
 
 import datagen
+from conftest import compare_with_reference
 
 pytestmark = pytest.mark.gpu
 
 TYPES = [("CHAR", 0, 1), ("USHORT", 3, 2), ("INT", 4, 4)]
 
+_ORACLE_CACHE = {}
 
-def _compress_both(hc, reflib, chunks, dtype, max_chunk):
+
+def _want(oracle, c: bytes, es: int, max_chunk: int, **kw) -> bytes:
+    """oracle.lz4_compress, remembered (the same chunks come back once per shape)"""
+    key = (hashlib.sha1(c).digest(), len(c), es, max_chunk, tuple(sorted(kw.items())))
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = oracle.lz4_compress(c, es, max_chunk, **kw)
+    return _ORACLE_CACHE[key]
+
+
+def _compress(hc, chunks, dtype, max_chunk, lib=None):
     import torch
     src = hc.batch.from_host_chunks(chunks, "cuda:0")
-    mine = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype)).compress(src, max_chunk)
+    out = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=lib).compress(src, max_chunk)
     torch.cuda.synchronize()
-    ref = None
-    if reflib is not None:
-        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=reflib).compress(src, max_chunk)
-        torch.cuda.synchronize()
-    return src, mine, ref
+    return src, out
+
+
+def _round_trip(hc, comp, chunks, dtype, cap=65536):
+    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
+    dec, actual, statuses = codec.decompress(comp, cap)
+    assert statuses.cpu().tolist() == [0] * len(chunks)
+    assert dec.to_host_chunks() == chunks
+    return codec
+
+
+def _reference_agrees(hc, chunks, dtype, max_chunk, want, what):
+    """a check for compare_with_reference: the reference build's bytes == want"""
+    def check(reflib):
+        _, ref = _compress(hc, chunks, dtype, max_chunk, lib=reflib)
+        refgot = ref.to_host_chunks()
+        for i in range(len(chunks)):
+            assert refgot[i] == want[i], f"{what} chunk {i}: oracle != reference build"
+    return check
 
 
 @pytest.mark.parametrize("tname,dtype,es", TYPES)
-def test_edge_chunks_bit_exact(hc, oracle, reflib, cuda, tname, dtype, es):
+def test_edge_chunks_bit_exact(hc, oracle, reflib, cuda, lz4_shape, tname, dtype, es):
     named = datagen.edge_chunks()
     # typed modes need sizeof(T)-aligned starts (true: 16-B stride) -- any length is legal
     chunks = [c for _, c in named]
+    wants = {}
     for max_chunk in (65536, 0, 1000):
-        src, mine, ref = _compress_both(hc, reflib, chunks, dtype, max_chunk)
+        src, mine = _compress(hc, chunks, dtype, max_chunk)
         got = mine.to_host_chunks()
-        refgot = ref.to_host_chunks() if ref is not None else None
+        wants[max_chunk] = [_want(oracle, c, es, max_chunk) for c in chunks]
         for i, (name, c) in enumerate(named):
-            want = oracle.lz4_compress(c, es, max_chunk)
-            assert got[i] == want, f"{name} {tname} max_chunk={max_chunk}: kernel != oracle"
-            if refgot is not None:
-                assert refgot[i] == want, f"{name} {tname} max_chunk={max_chunk}: oracle != reference"
-        # round trip through my decoder
-        codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
-        dec, actual, statuses = codec.decompress(mine, 65536)
-        assert statuses.cpu().tolist() == [0] * len(chunks)
-        assert dec.to_host_chunks() == chunks
+            assert got[i] == wants[max_chunk][i], f"{name} {tname} max_chunk={max_chunk} shape={lz4_shape}: kernel != oracle"
+        codec = _round_trip(hc, mine, chunks, dtype)
         assert codec.get_decompress_size(mine).cpu().tolist() == [len(c) for c in chunks]
+
+    def check(reflib):
+        for max_chunk in (65536, 0, 1000):
+            _reference_agrees(hc, chunks, dtype, max_chunk, wants[max_chunk], f"{tname} max_chunk={max_chunk}")(reflib)
+    compare_with_reference(reflib, "edge chunks", check)
 
 
 @pytest.mark.parametrize("tname,dtype,es", TYPES)
-def test_sparse_matches_walk_and_rollback(hc, oracle, reflib, cuda, tname, dtype, es):
+def test_sparse_matches_walk_and_rollback(hc, oracle, reflib, cuda, lz4_shape, tname, dtype, es):
     """Long match-less stretches that end in a match: the encoder's pipelined
     walk, its roll-back (match in the older of the two windows in flight, at
     any lane), its exits at the last full window, and the re-arming after a
     match.  More chunks than one workgroup holds, of different sizes, so that
-    waves draw tickets at different times."""
+    waves draw tickets at different times.  (Forced far shapes: their general,
+    match-less path on data they are never chosen for.)"""
     chunks = []
     for k, (every, length) in enumerate([(200, 4), (200, 9), (700, 5), (3000, 40), (61, 4), (64, 6), (5000, 300), (129, 4)]):
         for n in (65536, 65535 - 7 * k, 20000 + 13 * k, 257 + k):
             chunks.append(datagen.sparse_repeats(100 + k, n, every, length))
     chunks.append(bytes(np.random.default_rng(9).integers(0, 256, 65536, dtype=np.uint8)))  # no match at all
     chunks = [c[: len(c) // es * es] if es > 1 else c for c in chunks]
-    src, mine, ref = _compress_both(hc, reflib, chunks, dtype, 65536)
+    src, mine = _compress(hc, chunks, dtype, 65536)
     got = mine.to_host_chunks()
-    refgot = ref.to_host_chunks() if ref is not None else None
-    for i, c in enumerate(chunks):
-        want = oracle.lz4_compress(c, es, 65536)
-        assert got[i] == want, f"chunk {i} {tname}: kernel != oracle"
-        if refgot is not None:
-            assert refgot[i] == want, f"chunk {i} {tname}: oracle != reference"
-    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
-    dec, actual, statuses = codec.decompress(mine, 65536)
-    assert statuses.cpu().tolist() == [0] * len(chunks)
-    assert dec.to_host_chunks() == chunks
+    want = [_want(oracle, c, es, 65536) for c in chunks]
+    for i in range(len(chunks)):
+        assert got[i] == want[i], f"chunk {i} {tname} shape={lz4_shape}: kernel != oracle"
+    _round_trip(hc, mine, chunks, dtype)
+    compare_with_reference(reflib, "sparse matches", _reference_agrees(hc, chunks, dtype, 65536, want, tname))
 
 
 @pytest.mark.parametrize("tname,dtype,es", TYPES)
-def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, tname, dtype, es):
-    """A batch of data that compresses, larger than the LDS-table shape holds in
-    flight: the sampling kernel calls for the "far" shape (hash tables in the
-    temp buffer).  Checked: the counters it left in the temp buffer, that the
-    temp buffer behind them was used, and every chunk's bytes against the
-    oracle (48 distinct chunks, each 32 times: text, the harness's data, runs,
-    sparse repeats, ragged lengths, an empty chunk, and a few chunks of random
-    bytes, which take that kernel's match-less path) and the reference build."""
+def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, lz4_shape, tname, dtype, es):
+    """A batch of data that compresses: the sampling kernel calls for a "far"
+    shape (hash tables in the temp buffer or, for the waves that have one, in
+    LDS).  Checked: the counters it left in the temp buffer, and every chunk's
+    bytes against the oracle (48 distinct chunks, each 32 times: text, the
+    harness's data, runs, sparse repeats, ragged lengths, an empty chunk, and a
+    few chunks of random bytes, which take that kernel's match-less path) and
+    the reference build."""
     import torch
     rng = np.random.default_rng(5)
     base = []
@@ -99,7 +123,7 @@ def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, tname
     base = [c[: len(c) // es * es] for c in base]
     assert len(base) == 48
     chunks = base * 32
-    want = [oracle.lz4_compress(c, es, 65536) for c in base]
+    want = [_want(oracle, c, es, 65536) for c in base]
     src = hc.batch.from_host_chunks(chunks, "cuda:0")
     codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
     dst = hc.batch.alloc_batch(src.n, codec.max_output_chunk_size(65536), src.device)
@@ -108,56 +132,38 @@ def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, tname
     torch.cuda.synchronize()
     ticket, repeats, looked = temp[:12].view(torch.int32).cpu().tolist()
     assert ticket >= src.n
-    if os.environ.get("HIPCOMP_LZ4_SHAPE", "auto") == "auto":          # (a forced shape skips the sampling kernel)
+    if lz4_shape == "auto":                                             # (a forced shape skips the sampling kernel)
         assert looked > 0 and repeats * 4 > looked                     # the sampler's verdict: compressible
-        assert bool((temp[16 : 16 + 4 * 32768] != 0xAB).any().item())  # hash tables of the far shape were written
+    if lz4_shape in ("far", "farw"):
+        assert bool((temp[16 : 16 + 4 * 32768] != 0xAB).any().item())  # hash tables in the temp buffer were written
     got = dst.to_host_chunks()
     for i in range(len(chunks)):
-        assert got[i] == want[i % 48], f"chunk {i} {tname}: kernel != oracle"
-    if reflib is not None:
-        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=reflib).compress(src, 65536)
-        torch.cuda.synchronize()
-        refgot = ref.to_host_chunks()
-        for i in range(48):
-            assert refgot[i] == want[i], f"chunk {i} {tname}: oracle != reference"
-    dec, actual, statuses = codec.decompress(dst, 65536)
-    assert statuses.cpu().tolist() == [0] * len(chunks)
-    assert dec.to_host_chunks() == chunks
+        assert got[i] == want[i % 48], f"chunk {i} {tname} shape={lz4_shape}: kernel != oracle"
+    _round_trip(hc, dst, chunks, dtype)
+    compare_with_reference(reflib, "compressible batch", _reference_agrees(hc, base, dtype, 65536, want, tname))
 
 
 @pytest.mark.parametrize("tname,dtype,es", TYPES)
-def test_several_sequences_per_trip_corner_cases(hc, oracle, reflib, cuda, tname, dtype, es):
-    """The far shape's byte path takes several sequences off one trip to memory
+def test_several_sequences_per_trip_corner_cases(hc, oracle, reflib, cuda, lz4_shape, tname, dtype, es):
+    """The far shapes' lean form takes several sequences off one trip to memory
     (far_straight_several): periodic data with periods shorter than its span,
     tiny alphabets (lanes of one window in one table slot, matches that overlap
     their source), vocabulary text with near and far candidates, real text.  64
-    crafted chunks x 24 (the batch must be larger than what the LDS shape holds
-    for the sampler to choose "far"), every chunk against the oracle and the
-    reference build, then the round trip."""
-    import torch
+    crafted chunks x 24, every chunk against the oracle and the reference
+    build, then the round trip."""
     base = [c[: len(c) // es * es] for c in datagen.trip_corner_chunks()]
     chunks = base * 24
-    want = [oracle.lz4_compress(c, es, 65536) for c in base]
-    src = hc.batch.from_host_chunks(chunks, "cuda:0")
-    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
-    mine = codec.compress(src, 65536)
-    torch.cuda.synchronize()
+    want = [_want(oracle, c, es, 65536) for c in base]
+    src, mine = _compress(hc, chunks, dtype, 65536)
     got = mine.to_host_chunks()
     for i in range(len(chunks)):
-        assert got[i] == want[i % len(base)], f"chunk {i}: kernel != oracle"
-    if reflib is not None:
-        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=reflib).compress(src, 65536)
-        torch.cuda.synchronize()
-        refgot = ref.to_host_chunks()
-        for i in range(len(base)):
-            assert refgot[i] == want[i], f"chunk {i} {tname}: oracle != reference"
-    dec, actual, statuses = codec.decompress(mine, 65536)
-    assert statuses.cpu().tolist() == [0] * len(chunks)
-    assert dec.to_host_chunks() == chunks
+        assert got[i] == want[i % len(base)], f"chunk {i} shape={lz4_shape}: kernel != oracle"
+    _round_trip(hc, mine, chunks, dtype)
+    compare_with_reference(reflib, "trip corner cases", _reference_agrees(hc, base, dtype, 65536, want, tname))
 
 
 @pytest.mark.parametrize("tname,dtype,es", TYPES)
-def test_most_repetitive_batches_take_the_widest_span(hc, oracle, reflib, cuda, tname, dtype, es):
+def test_most_repetitive_batches_take_the_widest_span(hc, oracle, reflib, cuda, lz4_shape, tname, dtype, es):
     """When nearly every sampled word repeats (the harness's data, short periods,
     tiny alphabets) the far shape's lean form looks up 52 lanes per trip instead
     of 40: checked that the sampler says so, then every chunk against the oracle
@@ -173,7 +179,7 @@ def test_most_repetitive_batches_take_the_widest_span(hc, oracle, reflib, cuda, 
     base = [c[: len(c) // es * es] for c in base]
     assert len(base) == 32
     chunks = base * 48
-    want = [oracle.lz4_compress(c, es, 65536) for c in base]
+    want = [_want(oracle, c, es, 65536) for c in base]
     src = hc.batch.from_host_chunks(chunks, "cuda:0")
     codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
     dst = hc.batch.alloc_batch(src.n, codec.max_output_chunk_size(65536), src.device)
@@ -181,55 +187,37 @@ def test_most_repetitive_batches_take_the_widest_span(hc, oracle, reflib, cuda, 
     assert codec.compress_async(src, 65536, temp, dst) == 0
     torch.cuda.synchronize()
     ticket, repeats, looked = temp[:12].view(torch.int32).cpu().tolist()
-    if os.environ.get("HIPCOMP_LZ4_SHAPE", "auto") == "auto":
+    if lz4_shape == "auto":
         assert looked > 0 and repeats * 8 > looked * 7
     got = dst.to_host_chunks()
     for i in range(len(chunks)):
-        assert got[i] == want[i % len(base)], f"chunk {i} {tname}: kernel != oracle"
-    if reflib is not None:
-        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=reflib).compress(src, 65536)
-        torch.cuda.synchronize()
-        refgot = ref.to_host_chunks()
-        for i in range(len(base)):
-            assert refgot[i] == want[i], f"chunk {i} {tname}: oracle != reference"
-    dec, actual, statuses = codec.decompress(dst, 65536)
-    assert statuses.cpu().tolist() == [0] * len(chunks)
-    assert dec.to_host_chunks() == chunks
+        assert got[i] == want[i % len(base)], f"chunk {i} {tname} shape={lz4_shape}: kernel != oracle"
+    _round_trip(hc, dst, chunks, dtype)
+    compare_with_reference(reflib, "most repetitive batch", _reference_agrees(hc, base, dtype, 65536, want, tname))
 
 
 @pytest.mark.parametrize("tname,dtype,es", TYPES)
-def test_runs_of_element_sized_values(hc, oracle, reflib, cuda, tname, dtype, es):
+def test_runs_of_element_sized_values(hc, oracle, reflib, cuda, lz4_shape, tname, dtype, es):
     """Run-length data whose values are of the element's size (the wide form's
     runs trip for 2- and 4-byte elements: all sequences of 48 lanes from one trip
     to the table), run lengths up to 2 .. 60 elements, ragged chunk lengths: every
     chunk against the oracle and the reference build, then the round trip."""
-    import torch
     base = []
     for k, longest in enumerate((2, 3, 4, 6, 8, 12, 16, 24, 32, 40, 60, 5)):
         for j in range(4):
             base.append(datagen.runs_of_elements(800 + 10 * k + j, 65536 - 4 * (k + 7 * j), es, longest))
     assert len(base) == 48
     chunks = base * 32
-    want = [oracle.lz4_compress(c, es, 65536) for c in base]
-    src = hc.batch.from_host_chunks(chunks, "cuda:0")
-    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
-    mine = codec.compress(src, 65536)
-    torch.cuda.synchronize()
+    want = [_want(oracle, c, es, 65536) for c in base]
+    src, mine = _compress(hc, chunks, dtype, 65536)
     got = mine.to_host_chunks()
     for i in range(len(chunks)):
-        assert got[i] == want[i % len(base)], f"chunk {i} {tname}: kernel != oracle"
-    if reflib is not None:
-        ref = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype), lib=reflib).compress(src, 65536)
-        torch.cuda.synchronize()
-        refgot = ref.to_host_chunks()
-        for i in range(len(base)):
-            assert refgot[i] == want[i], f"chunk {i} {tname}: oracle != reference"
-    dec, actual, statuses = codec.decompress(mine, 65536)
-    assert statuses.cpu().tolist() == [0] * len(chunks)
-    assert dec.to_host_chunks() == chunks
+        assert got[i] == want[i % len(base)], f"chunk {i} {tname} shape={lz4_shape}: kernel != oracle"
+    _round_trip(hc, mine, chunks, dtype)
+    compare_with_reference(reflib, "runs of elements", _reference_agrees(hc, base, dtype, 65536, want, tname))
 
 
-def test_small_tables_many_waves_per_group(hc, oracle, cuda):
+def test_small_tables_many_waves_per_group(hc, oracle, cuda, lz4_shape):
     """max_chunk below 16 KiB: smaller hash tables, up to 16 waves (= chunks
     in flight) per workgroup, batch sizes that do not fill the last group."""
     rng = np.random.default_rng(21)
@@ -255,7 +243,7 @@ def test_small_tables_many_waves_per_group(hc, oracle, cuda):
         assert dec.to_host_chunks() == chunks
 
 
-def test_temp_buffer_of_exactly_the_contract_size(hc, oracle, cuda):
+def test_temp_buffer_of_exactly_the_contract_size(hc, oracle, cuda, lz4_shape):
     """The encoder keeps its chunk ticket counter in the temp buffer.  The
     contract size can be smaller than that counter (tiny max_chunk, tiny
     batch) and the caller's pointer need not be 4-byte aligned: nothing
@@ -278,7 +266,7 @@ def test_temp_buffer_of_exactly_the_contract_size(hc, oracle, cuda):
             assert (a[: 16 + shift] == 0xA5).all() and (a[16 + shift + need:] == 0xA5).all(), (max_chunk, shift)
 
 
-def test_large_chunks_beyond_64k(hc, oracle, reflib, cuda):
+def test_large_chunks_beyond_64k(hc, oracle, reflib, cuda, lz4_shape):
     """> 65536 elements: exercises the 16-bit position wrap of the hash table.
     In typed modes the reference truncates byte offsets > 65535 (a corrupt
     stream); the product rejects those candidates instead -- the one place
@@ -286,40 +274,39 @@ def test_large_chunks_beyond_64k(hc, oracle, reflib, cuda):
     rng = np.random.default_rng(5)
     base = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))
     chunks = [(base * 100)[:250000], datagen.text_like(3, 200001), bytes(rng.integers(0, 3, 150000, dtype=np.uint8))]
+    faithful = {}
     for dtype, es in ((0, 1), (4, 4)):
-        src, mine, ref = _compress_both(hc, reflib, chunks, dtype, 250000)
+        src, mine = _compress(hc, chunks, dtype, 250000)
         got = mine.to_host_chunks()
-        refgot = ref.to_host_chunks() if ref is not None else None
+        faithful[es] = [_want(oracle, c, es, 250000, valid_offsets=False) for c in chunks]
         for i, c in enumerate(chunks):
-            assert got[i] == oracle.lz4_compress(c, es, 250000, valid_offsets=True)
-            faithful = oracle.lz4_compress(c, es, 250000, valid_offsets=False)
-            if refgot is not None:
-                assert refgot[i] == faithful, "oracle (reference-faithful) != reference build"
+            assert got[i] == _want(oracle, c, es, 250000, valid_offsets=True), (i, es, lz4_shape)
             if es == 1:
-                assert got[i] == faithful
-        codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
-        dec, actual, statuses = codec.decompress(mine, 250016)
-        assert statuses.cpu().tolist() == [0, 0, 0]
-        assert dec.to_host_chunks() == chunks
+                assert got[i] == faithful[es][i]
+        _round_trip(hc, mine, chunks, dtype, cap=250016)
     # the reference's own typed stream of the text chunk does not decode to the input
-    bad = oracle.lz4_compress(chunks[1], 4, 250000, valid_offsets=False)
-    st, out = oracle.lz4_decompress(bad, 250016)
+    st, out = oracle.lz4_decompress(faithful[4][1], 250016)
     assert out != chunks[1]
 
+    def check(reflib):
+        for dtype, es in ((0, 1), (4, 4)):
+            _reference_agrees(hc, chunks, dtype, 250000, faithful[es], "reference-faithful oracle, elem %d" % es)(reflib)
+    compare_with_reference(reflib, "chunks beyond 64 KiB", check)
 
-def test_reference_harness_batches(hc, oracle, reflib, cuda):
+
+def test_reference_harness_batches(hc, oracle, reflib, cuda, lz4_shape):
     """The six batches of tests/test_batch_c_api.h:772-777 with its data."""
     import torch
+    mine_all = []
     for chunks in datagen.harness_batches():
         max_chunk = max(len(c) for c in chunks)
         for dtype, es in ((0, 1), (4, 4)):
-            src, mine, ref = _compress_both(hc, reflib, chunks, dtype, max_chunk)
+            src, mine = _compress(hc, chunks, dtype, max_chunk)
             got = mine.to_host_chunks()
-            if ref is not None:
-                assert got == ref.to_host_chunks(), "kernel != reference build"
+            mine_all.append((chunks, dtype, max_chunk, got))
             step = max(1, len(chunks) // 64)  # oracle on a sample (the reference build covers all)
             for i in range(0, len(chunks), step):
-                assert got[i] == oracle.lz4_compress(chunks[i], es, max_chunk)
+                assert got[i] == _want(oracle, chunks[i], es, max_chunk), (i, es, lz4_shape)
             codec = hc.batch.Codec("LZ4", hc.LZ4Opts(dtype))
             # GetDecompressSize == input bytes (harness :366-384)
             assert codec.get_decompress_size(mine).cpu().tolist() == [len(c) for c in chunks]
@@ -332,6 +319,12 @@ def test_reference_harness_batches(hc, oracle, reflib, cuda):
             torch.cuda.synchronize()
             dec2.sizes = src.sizes
             assert dec2.to_host_chunks() == chunks
+
+    def check(reflib):
+        for chunks, dtype, max_chunk, got in mine_all:
+            _, ref = _compress(hc, chunks, dtype, max_chunk, lib=reflib)
+            assert got == ref.to_host_chunks(), "kernel != reference build"
+    compare_with_reference(reflib, "the harness's six batches (all chunks)", check)
 
 
 def test_crash_safe_raw_input_is_rejected(hc, cuda):

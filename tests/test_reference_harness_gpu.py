@@ -1,0 +1,30 @@
+"""The reference's OWN C harness against the product library: reference
+tests/test_{lz4batch,snappy_batch,cascadedbatch}_c_api.c (five-line stubs over
+tests/test_batch_c_api.h:225-790 -- six batches of 1 .. 10 025 chunks, the nullptr
+forms of the API, CRASH_SAFE decompression of raw input) compiled as C99 from where
+they lie against THIS repo's include/ and linked with hipcomp-core_amd/lib/libhipcomp.so
+(oracle/Makefile, binaries under the git-ignored oracle/_ref/).  Each runs as a child
+process and must exit 0: the drop-in claim of INTEGRATION.md, proved with the caller
+the reference ships."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["lz4batch", "snappy_batch", "cascadedbatch"])
+def test_reference_c_harness_passes_on_the_product_library(cuda, name):
+    exe = os.path.join(ROOT, "oracle", "_ref", "harness_" + name)
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} absent (built by oracle/Makefile where /root/reference exists)")
+    # the binary must have bound the product library, not another libhipcomp.so
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    bound = [ln for ln in ldd.splitlines() if "libhipcomp.so" in ln]
+    assert bound and os.path.realpath(bound[0].split("=>")[1].split("(")[0].strip()) == os.path.realpath(
+        os.path.join(ROOT, "hipcomp-core_amd", "lib", "libhipcomp.so")), ldd
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "failed" not in r.stdout.lower(), r.stdout[-2000:]

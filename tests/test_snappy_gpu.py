@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import datagen
+from conftest import compare_with_reference
 from test_snappy_oracle_cpu import copy_tag, literal_tag, varint
 
 pytestmark = pytest.mark.gpu
@@ -31,25 +32,26 @@ def test_compress_bit_exact_and_roundtrip(hc, oracle, reflib, cuda):
     mine = codec.compress(src)
     torch.cuda.synchronize()
     got = mine.to_host_chunks()
-    refgot = None
-    if reflib is not None:
-        r = hc.batch.Codec("Snappy", lib=reflib).compress(src)
-        torch.cuda.synchronize()
-        refgot = r.to_host_chunks()
+    want = [oracle.snappy_compress(c) for c in chunks]
     for i, (name, c) in enumerate(named):
-        want = oracle.snappy_compress(c)
-        assert got[i] == want, f"{name}: kernel != oracle"
-        if refgot is not None:
-            assert refgot[i] == want, f"{name}: oracle != reference build"
+        assert got[i] == want[i], f"{name}: kernel != oracle"
     assert codec.get_decompress_size(mine).cpu().tolist() == [len(c) for c in chunks]
     dec, actual, statuses = codec.decompress(mine, 65536)
     assert statuses.cpu().tolist() == [0] * len(chunks)
     assert actual.cpu().tolist() == [len(c) for c in chunks]
     assert dec.to_host_chunks() == chunks
-    if reflib is not None:  # the reference decodes our streams too
+
+    def check(reflib):
+        r = hc.batch.Codec("Snappy", lib=reflib).compress(src)
+        torch.cuda.synchronize()
+        refgot = r.to_host_chunks()
+        for i, (name, c) in enumerate(named):
+            assert refgot[i] == want[i], f"{name}: oracle != reference build"
+        # the reference decodes our streams too
         rdec, ractual, rstat = hc.batch.Codec("Snappy", lib=reflib).decompress(mine, 65536)
         assert rstat.cpu().tolist() == [0] * len(chunks)
         assert rdec.to_host_chunks() == chunks
+    compare_with_reference(reflib, "Snappy edge chunks", check)
 
 
 def test_several_elements_per_trip_corner_cases(hc, oracle, reflib, cuda):
@@ -68,29 +70,29 @@ def test_several_elements_per_trip_corner_cases(hc, oracle, reflib, cuda):
     want = [oracle.snappy_compress(c) for c in chunks]
     for i in range(len(chunks)):
         assert got[i] == want[i], f"chunk {i}: kernel != oracle"
-    if reflib is not None:
+    dec, actual, statuses = codec.decompress(mine, 65536)
+    assert statuses.cpu().tolist() == [0] * len(chunks)
+    assert dec.to_host_chunks() == chunks
+
+    def check(reflib):
         r = hc.batch.Codec("Snappy", lib=reflib).compress(src)
         torch.cuda.synchronize()
         refgot = r.to_host_chunks()
         for i in range(len(chunks)):
             assert refgot[i] == want[i], f"chunk {i}: oracle != reference build"
-    dec, actual, statuses = codec.decompress(mine, 65536)
-    assert statuses.cpu().tolist() == [0] * len(chunks)
-    assert dec.to_host_chunks() == chunks
+    compare_with_reference(reflib, "Snappy trip corner cases", check)
 
 
 def test_reference_harness_batches(hc, oracle, reflib, cuda):
     import torch
+    mine_all = []
     for bi, chunks in enumerate(datagen.harness_batches()):
         src = hc.batch.from_host_chunks(chunks, "cuda:0")
         codec = hc.batch.Codec("Snappy")
         mine = codec.compress(src)
         torch.cuda.synchronize()
         got = mine.to_host_chunks()
-        if reflib is not None:
-            r = hc.batch.Codec("Snappy", lib=reflib).compress(src)
-            torch.cuda.synchronize()
-            assert got == r.to_host_chunks(), f"batch {bi}: kernel != reference build"
+        mine_all.append((bi, src, got))
         step = max(1, len(chunks) // 64)
         for i in range(0, len(chunks), step):
             assert got[i] == oracle.snappy_compress(chunks[i])
@@ -102,6 +104,13 @@ def test_reference_harness_batches(hc, oracle, reflib, cuda):
         torch.cuda.synchronize()
         dec2.sizes = src.sizes
         assert dec2.to_host_chunks() == chunks
+
+    def check(reflib):
+        for bi, src, got in mine_all:
+            r = hc.batch.Codec("Snappy", lib=reflib).compress(src)
+            torch.cuda.synchronize()
+            assert got == r.to_host_chunks(), f"batch {bi}: kernel != reference build"
+    compare_with_reference(reflib, "Snappy, the harness's batches (all chunks)", check)
 
 
 def test_reference_decoder_vectors_and_large_tokens(hc, cuda):
@@ -194,10 +203,12 @@ def test_large_chunks(hc, oracle, reflib, cuda):
     got = mine.to_host_chunks()
     for i, c in enumerate(chunks):
         assert got[i] == oracle.snappy_compress(c), i
-    if reflib is not None:
-        r = hc.batch.Codec("Snappy", lib=reflib).compress(src)
-        torch.cuda.synchronize()
-        assert r.to_host_chunks() == got
     dec, actual, statuses = codec.decompress(mine, 1 << 20)
     assert statuses.cpu().tolist() == [0] * len(chunks)
     assert dec.to_host_chunks() == chunks
+
+    def check(reflib):
+        r = hc.batch.Codec("Snappy", lib=reflib).compress(src)
+        torch.cuda.synchronize()
+        assert r.to_host_chunks() == got
+    compare_with_reference(reflib, "Snappy large chunks", check)

@@ -283,11 +283,11 @@ struct Core
 
   Layout layout(size_t n) const { return layout_of(n, format_header_bytes); }
 
-  // scratch: chunk lists of a slab, three words for the LZ4 compress kernels, the slots, and
-  // (LZ4) hash tables for the compress kernel's "far" shape, one per chunk of a slab
+  // scratch: chunk lists of a slab, the slots, and (LZ4) the compress launcher's own temp space
+  // (its header, routing lists and hash tables for a slab: lz4_launch.hpp)
   size_t lists_bytes() const { return (size_t)slab * (8 + 8 + 8 + 8 + 8 + 4) + 64; }
-  size_t table_bytes() const { return codec == LZ4 ? (size_t)(ht_size < 8 ? 8 : ht_size) * sizeof(uint16_t) : 0; }
-  size_t scratch_bytes() const { return lists_bytes() + (size_t)slab * slot_bytes + 16 + (size_t)slab * table_bytes(); }
+  size_t lz4_temp_bytes() const { return codec == LZ4 ? lz4_compress_temp_bytes_used(ht_size, slab) : 0; }
+  size_t scratch_bytes() const { return lists_bytes() + (size_t)slab * slot_bytes + 16 + lz4_temp_bytes(); }
   uint8_t* ensure_scratch()
   {
     if (!scratch) {
@@ -315,9 +315,8 @@ struct Core
     const uint8_t** in_ptrs = reinterpret_cast<const uint8_t**>(s);
     size_t* in_bytes = reinterpret_cast<size_t*>(s + (size_t)slab * 8);
     uint8_t** out_ptrs = reinterpret_cast<uint8_t**>(s + (size_t)slab * 16);
-    uint32_t* words = reinterpret_cast<uint32_t*>(s + (size_t)slab * 44);
     uint8_t* slots = s + lists_bytes();
-    uint16_t* tables = reinterpret_cast<uint16_t*>(
+    uint8_t* lz4_temp = reinterpret_cast<uint8_t*>(
         (reinterpret_cast<uintptr_t>(slots + (size_t)slab * slot_bytes) + 15) & ~uintptr_t(15));
     header_kernel<<<1, 1, 0, stream>>>(comp_buffer, cfg.uncompressed_buffer_size, n, chunk_bytes, (uint32_t)lay.data,
                                        format, format_header, format_header_bytes, cfg.get_status());
@@ -330,7 +329,7 @@ struct Core
       size_t* sizes = reinterpret_cast<size_t*>(comp_buffer + lay.sizes) + first;
       switch (codec) {
       case LZ4:
-        check(lz4_launch_compress(in_ptrs, in_bytes, out_ptrs, sizes, ht_size, count, lz4_elem, words, tables, slab,
+        check(lz4_launch_compress(in_ptrs, in_bytes, out_ptrs, sizes, ht_size, count, lz4_elem, lz4_temp, lz4_temp_bytes(),
                                   chunk_bytes, lz4_mode_from_environment(), stream),
               "LZ4Manager::compress");
         break;

@@ -8,11 +8,12 @@
 //     LZ4Batch.cpp:76,160,177 call CHECK_NOT_NULL outside the try block);
 //   * batch_size == 0 is a successful no-op (the reference launches a
 //     zero-sized grid and reports the resulting HIP error);
-//   * of device_temp_ptr the first 16 bytes hold the chunk ticket counter of
-//     the persistent compress kernels and three sampling counters; the rest
-//     holds hash tables only for data that compresses well (one per resident
-//     wave, not one per chunk: lz4_kernels.hip "far"), otherwise the tables
-//     live in LDS.  temp_bytes is checked against the contract size, so
+//   * of device_temp_ptr the first 64 bytes hold the chunk ticket counters of
+//     the persistent compress kernels, list lengths and sample totals, behind
+//     them lie the routing kernel's chunk lists (16 bytes per chunk) and hash
+//     tables for data that compresses (one per resident device-table wave, not
+//     one per chunk: lz4_far.hiph); the other tables live in LDS
+//     (lz4_launch.hpp).  temp_bytes is checked against the contract size, so
 //     callers sized for the reference keep working and callers that
 //     under-allocate keep failing the same way.  As with the reference, one
 //     temp buffer serves one compress call at a time.
@@ -114,31 +115,11 @@ hipcompStatus_t hipcompBatchedLZ4CompressAsync(
   if (batch_size > 0x7FFFFFFFull) // the ticket counter runs past batch_size by up to waves x 64
     return fail(fn, "batch_size must be below 2^31");
   HCAMD_DEVICE_POINTER(fn, device_temp_ptr);
-  // the chunk ticket counter and the three counters of the sampling kernel: the
-  // first four 4-byte aligned words of the temp buffer -- if the (contract-
-  // sized) buffer is too small to hold them, the kernel runs without
-  uint32_t* ticket = nullptr;
-  // behind them, 16-byte aligned: hash tables of the "far" shape, as many as fit
-  uint16_t* far_tables = nullptr;
-  size_t far_capacity = 0;
-  {
-    const uintptr_t base = reinterpret_cast<uintptr_t>(device_temp_ptr);
-    const uintptr_t aligned = (base + 3u) & ~uintptr_t(3);
-    if (aligned + 4 * sizeof(uint32_t) <= base + temp_bytes) {
-      ticket = reinterpret_cast<uint32_t*>(aligned);
-      const uintptr_t tables = (aligned + 4 * sizeof(uint32_t) + 15u) & ~uintptr_t(15);
-      if (tables < base + temp_bytes) {
-        far_tables = reinterpret_cast<uint16_t*>(tables);
-        far_capacity = (base + temp_bytes - tables) / ((ht < 8 ? 8 : ht) * sizeof(uint16_t));
-      }
-    }
-  }
-
   const hipError_t e = lz4_launch_compress(
       reinterpret_cast<const uint8_t* const*>(device_uncompressed_ptrs),
       device_uncompressed_bytes,
       reinterpret_cast<uint8_t* const*>(device_compressed_ptrs),
-      device_compressed_bytes, (uint32_t)ht, batch_size, s, ticket, far_tables, far_capacity,
+      device_compressed_bytes, (uint32_t)ht, batch_size, s, device_temp_ptr, temp_bytes,
       max_uncompressed_chunk_bytes,
       lz4_mode_from_environment(), stream);
   if (e != hipSuccess)

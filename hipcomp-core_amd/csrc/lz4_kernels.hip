@@ -115,9 +115,9 @@ namespace {
 
 typedef void (*MixKernel)(
     const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t, uint32_t,
-    uint32_t, uint32_t*, uint32_t, const uint32_t*);
+    uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint32_t*);
 typedef void (*FarKernel)(const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint16_t*,
-                          uint32_t, uint32_t*, uint32_t, const uint32_t*);
+                          uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint32_t*);
 
 MixKernel mix_kernel_for(int elem_size)
 {
@@ -131,17 +131,6 @@ FarKernel far_kernel_for(int elem_size, bool wide)
                                                                                : lz4_compress_kernel_far<4, true>;
   return elem_size == 1 ? lz4_compress_kernel_far<1, false> : elem_size == 2 ? lz4_compress_kernel_far<2, false>
                                                                               : lz4_compress_kernel_far<4, false>;
-}
-
-typedef void (*BothKernel)(const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint16_t*,
-                           uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*);
-BothKernel both_kernel_for(int elem_size, bool wide)
-{
-  if (wide)
-    return elem_size == 1 ? lz4_compress_kernel_both<1, true> : elem_size == 2 ? lz4_compress_kernel_both<2, true>
-                                                                                : lz4_compress_kernel_both<4, true>;
-  return elem_size == 1 ? lz4_compress_kernel_both<1, false> : elem_size == 2 ? lz4_compress_kernel_both<2, false>
-                                                                               : lz4_compress_kernel_both<4, false>;
 }
 
 // more than 64 KiB of dynamic LDS has to be asked for, once per kernel and device
@@ -160,7 +149,7 @@ hipError_t raise_dynamic_lds_limit()
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(mix_kernel_for(es)),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int wide = 0; wide < 2 && r == hipSuccess; ++wide)
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(both_kernel_for(es, wide != 0)),
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(far_kernel_for(es, wide != 0)),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   g_lds_raised[dev].store(r == hipSuccess ? 1 : -(int)r, std::memory_order_release);
@@ -235,118 +224,221 @@ Lz4Mode lz4_mode_from_environment()
     return Lz4Mode::Mix;
   if (e && std::strcmp(e, "far") == 0)
     return Lz4Mode::Far;
+  if (e && std::strcmp(e, "fars") == 0)
+    return Lz4Mode::FarSparse;
   if (e && std::strcmp(e, "farw") == 0)
     return Lz4Mode::FarWide;
   return Lz4Mode::Auto;
 }
 
 namespace {
-// Measurement knob HIPCOMP_LZ4_BOTH="near,far,slots": the far shapes run as the "both"
-// kernel with that many LDS-table waves and device-table waves per workgroup and that
-// many scratch slots per wave (a power of two).
-struct BothGeometry
+
+// Launch geometry of the far kernel for one class of data (lz4_far.hiph, above
+// lz4_compress_kernel_far): per workgroup `near` waves with their table in LDS
+// and `far` waves with their table in the temp buffer, `slots` scratch slots per
+// wave, `groups` workgroups.
+struct FarGeometry
 {
-  uint32_t near = 0, far = 0, slots = 0;
-  bool on() const { return near + far > 0; }
+  uint32_t near, far, slots, groups, lds_bytes;
+  uint32_t waves() const { return near + far; }
 };
-BothGeometry both_from_environment()
+
+// Measurement knob HIPCOMP_LZ4_GEOMETRY="near,far,slots": that geometry for every
+// far-type launch, as many workgroups as fit a CU.
+bool geometry_from_environment(uint32_t& near, uint32_t& far, uint32_t& slots)
 {
-  BothGeometry g;
-  const char* e = std::getenv("HIPCOMP_LZ4_BOTH");
+  const char* e = std::getenv("HIPCOMP_LZ4_GEOMETRY");
   unsigned a = 0, b = 0, c = 0;
-  if (e && std::sscanf(e, "%u,%u,%u", &a, &b, &c) == 3 && a + b >= 1 && a + b <= (unsigned)kBothMaxWavesPerGroup
+  if (e && std::sscanf(e, "%u,%u,%u", &a, &b, &c) == 3 && a + b >= 1 && a + b <= (unsigned)kFarMaxWavesPerGroup
       && c >= 64 && c <= 4096 && (c & (c - 1)) == 0) {
-    g.near = a;
-    g.far = b;
-    g.slots = c;
+    near = a;
+    far = b;
+    slots = c;
+    return true;
   }
+  return false;
+}
+
+uint32_t groups_per_cu(uint32_t lds_bytes, uint32_t waves)
+{
+  uint32_t g = kLdsPerCu / round_up(lds_bytes ? lds_bytes : 1u, kLdsGranule);
+  if (g > 8)
+    g = 8;
+  if (g * waves > 32)
+    g = 32 / waves;
   return g;
 }
+
+FarGeometry far_geometry(uint32_t ht_size, uint32_t cls, size_t batch, size_t far_capacity)
+{
+  const uint32_t table = 2u * (ht_size < 8 ? 8u : ht_size);
+  const uint32_t cus = (uint32_t)num_cus_of_current_device();
+  FarGeometry g = {};
+  uint32_t near = 0, far = 0, slots = 0;
+  if (geometry_from_environment(near, far, slots)) {
+    g.near = near;
+    g.far = far;
+    g.slots = slots;
+    g.lds_bytes = near * (table + 2u * slots) + far * 2u * slots;
+    uint32_t per_cu = g.lds_bytes <= kLdsPerCu ? groups_per_cu(g.lds_bytes, g.waves()) : 0;
+    g.groups = per_cu * cus;
+  } else {
+    // few chunks: a wave with its table in LDS for each of them, as far as LDS goes
+    const uint32_t lone_lds = table + 2u * kFarScratchSlots;
+    const uint32_t lone_per_cu = lone_lds <= kLdsPerCu ? groups_per_cu(lone_lds, 1) : 0;
+    if (lone_per_cu > 0 && batch <= (size_t)lone_per_cu * cus) {
+      g.near = 1;
+      g.far = 0;
+      g.slots = kFarScratchSlots;
+      g.lds_bytes = lone_lds;
+      g.groups = (uint32_t)batch;
+      return g;
+    }
+    // else: workgroups of one LDS-table wave and as many device-table waves as fill the CU's 32
+    // wave slots (dense, wide) or three (sparse), as many workgroups per CU as LDS holds
+    g.slots = 512;
+    g.near = 1;
+    uint32_t best = 0;
+    for (uint32_t per_cu = 8; per_cu >= 1; --per_cu) {
+      const uint32_t nf = 32 / per_cu - 1;
+      const uint32_t lds = table + (1 + nf) * 2u * g.slots;
+      if (lds <= kLdsPerCu && kLdsPerCu / round_up(lds, kLdsGranule) >= per_cu) {
+        best = per_cu;
+        g.far = nf;
+        break;
+      }
+    }
+    if (best == 0) { // (tables beyond what LDS holds: device-table waves only)
+      g.near = 0;
+      g.far = 4;
+      g.slots = kFarScratchSlots;
+      best = 8;
+    }
+    if (cls == kClassSparse && g.near > 0 && g.far > 3)
+      g.far = 3;
+    g.groups = best * cus;
+  }
+  // no more device-table waves than the batch needs and the temp buffer has tables for
+  if (g.groups > 0 && g.far > 0) {
+    const size_t want = (batch + g.groups - 1) / g.groups; // waves per workgroup that have a chunk
+    if (want < g.waves())
+      g.far = (uint32_t)(want > g.near ? want - g.near : 0);
+    if ((size_t)g.groups * g.far > far_capacity)
+      g.far = (uint32_t)(far_capacity / g.groups);
+    if (g.near == 0 && g.far == 0)
+      g.groups = 0;
+  }
+  g.lds_bytes = g.near * (table + 2u * g.slots) + g.far * 2u * g.slots;
+  if (g.groups > 0 && (size_t)g.groups * g.waves() > batch + g.waves() - 1)
+    g.groups = (uint32_t)((batch + g.waves() - 1) / g.waves());
+  return g;
+}
+
 } // namespace
+
+#ifdef HC_TRIP_STATS
+// (measurement build only; the name makes it pass the export map)
+extern "C" int hipcompBatchedLZ4DebugTripStats(uint32_t* host16, int reset)
+{
+  uint32_t zeros[16] = {};
+  if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_trip_stats), sizeof(zeros)) != hipSuccess)
+    return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_trip_stats), zeros, sizeof(zeros)) != hipSuccess)
+    return 2;
+  return 0;
+}
+#endif
+
+size_t lz4_compress_temp_bytes_used(uint32_t ht_size, size_t batch)
+{
+  // header, the four class lists, alignment, one table per chunk but no more than the chip holds waves
+  const size_t tables = batch < 8192 ? batch : 8192;
+  return 4 + kHeaderWords * sizeof(uint32_t) + kNumClasses * batch * sizeof(uint32_t) + 16
+         + tables * (size_t)(ht_size < 8 ? 8 : ht_size) * sizeof(uint16_t);
+}
 
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, uint32_t* scratch, uint16_t* far_tables, size_t far_capacity,
+    size_t batch, int elem_size, void* temp, size_t temp_bytes,
     size_t max_chunk_bytes, Lz4Mode mode, hipStream_t stream)
 {
-  const Lz4CompressShape mix = lz4_compress_shape_mix(ht_size, batch);
-  // far: as many workgroups as the chip holds and the caller's buffer has tables for
-  Lz4CompressShape far = {};
-  far.plain = kFarWavesPerGroup;
-  far.lds_bytes = kFarWavesPerGroup * kFarScratchSlots * (uint32_t)sizeof(uint16_t);
-  const uint32_t far_groups_per_cu = [] { // (measurement knob: fewer resident waves)
-    const char* e = std::getenv("HIPCOMP_LZ4_FAR_GROUPS");
-    const int v = e ? std::atoi(e) : 0;
-    return (uint32_t)(v >= 1 && v <= kFarGroupsPerCu ? v : kFarGroupsPerCu);
-  }();
-  far.groups = (uint32_t)num_cus_of_current_device() * far_groups_per_cu;
-  if ((size_t)far.groups * kFarWavesPerGroup > far_capacity)
-    far.groups = (uint32_t)(far_capacity / kFarWavesPerGroup);
-  // it needs the ticket counter, and pays once the batch is more than the mix
-  // shape has in flight at once (whose waves are the faster ones)
-  const bool far_possible = scratch != nullptr && far_tables != nullptr && far.groups > 0;
-  if ((mode == Lz4Mode::Far || mode == Lz4Mode::FarWide) && !far_possible) // (forced by the environment)
-    mode = Lz4Mode::Mix;
-  if (mode == Lz4Mode::Auto
-      && !(far_possible && far.groups * far.waves() > mix.groups * mix.waves() && batch > (size_t)mix.groups * mix.waves()))
-    mode = Lz4Mode::Mix;
+  // ---- the temp buffer: header (ticket counters, list lengths, sample totals), the class
+  // lists of the routing kernel, hash tables for the device-table waves of the far kernel --
+  // as much of that as the (contract-sized) buffer holds
+  uint32_t* header = nullptr;
+  uint32_t* lists = nullptr;
+  uint16_t* far_tables = nullptr;
+  size_t far_capacity = 0;
+  if (temp != nullptr) {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(temp), end = base + temp_bytes;
+    const uintptr_t aligned = (base + 3u) & ~uintptr_t(3);
+    if (aligned + kHeaderWords * sizeof(uint32_t) <= end) {
+      header = reinterpret_cast<uint32_t*>(aligned);
+      uintptr_t at = aligned + kHeaderWords * sizeof(uint32_t);
+      if (at + kNumClasses * batch * sizeof(uint32_t) <= end) {
+        lists = reinterpret_cast<uint32_t*>(at);
+        at += kNumClasses * batch * sizeof(uint32_t);
+      }
+      const uintptr_t tables = (at + 15u) & ~uintptr_t(15);
+      if (tables < end) {
+        far_tables = reinterpret_cast<uint16_t*>(tables);
+        far_capacity = (end - tables) / ((size_t)(ht_size < 8 ? 8 : ht_size) * sizeof(uint16_t));
+      }
+    }
+  }
   const hipError_t raised = raise_dynamic_lds_limit();
   if (raised != hipSuccess)
     return raised;
-  uint32_t* ticket = scratch;
-  const uint32_t* chosen = nullptr; // the sampling kernel's counters, if it runs
-  if (scratch) {
-    const hipError_t e = hipMemsetAsync(scratch, 0, 4 * sizeof(uint32_t), stream);
-    if (e != hipSuccess)
-      return e;
-    if (mode == Lz4Mode::Auto) {
-      lz4_sample_kernel<<<kSampleChunks, kWave, 0, stream>>>(in_ptrs, in_bytes, (uint32_t)batch, scratch + 1);
-      chosen = scratch + 1;
-    }
-  }
+  const Lz4CompressShape mix = lz4_compress_shape_mix(ht_size, batch);
   // about 16 KiB of input per ticket, but at least 4 tickets per wave so
   // that the last ones even out the load
-  auto chunks_per_ticket = [&](const Lz4CompressShape& sh) {
+  auto chunks_per_ticket = [&](size_t all_waves) {
     uint32_t per_ticket = 1;
-    const size_t all_waves = (size_t)sh.groups * sh.waves();
     while (per_ticket < 64 && (size_t)per_ticket * (max_chunk_bytes ? max_chunk_bytes : 1) < 16384
            && (size_t)per_ticket * 2 * 4 * all_waves <= batch)
       per_ticket *= 2;
     return per_ticket;
   };
-  if (mode != Lz4Mode::Far && mode != Lz4Mode::FarWide) {
+  auto launch_mix = [&](const uint32_t* count, const uint32_t* list) {
+    uint32_t* ticket = header ? header + kClassMix : nullptr;
     // ticket == nullptr: no persistent workgroups, one chunk per wave
     const dim3 grid(ticket ? mix.groups : (unsigned)((batch + mix.waves() - 1) / mix.waves()));
     mix_kernel_for(elem_size)<<<grid, dim3(mix.waves() * kWave), mix.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
-        (uint32_t)batch, ticket, chunks_per_ticket(mix), chosen);
+        (uint32_t)batch, ticket, chunks_per_ticket((size_t)mix.groups * mix.waves()), count, list);
+  };
+  auto launch_far = [&](uint32_t cls, const uint32_t* count, const uint32_t* list) -> bool {
+    const FarGeometry g = far_geometry(ht_size, cls, batch, far_tables ? far_capacity : 0);
+    if (g.groups == 0 || g.lds_bytes > kLdsPerCu)
+      return false;
+    far_kernel_for(elem_size, cls == kClassWide)<<<dim3(g.groups), dim3(g.waves() * kWave), g.lds_bytes, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, g.near, g.slots,
+        cls == kClassDense ? (uint32_t)kFarSpanMost : (uint32_t)kFarSpan, (uint32_t)batch, header + cls,
+        chunks_per_ticket((size_t)g.groups * g.waves()), count, list);
+    return true;
+  };
+  if (!header) { // (a temp buffer too small for a ticket counter)
+    launch_mix(nullptr, nullptr);
+    return hipSuccess;
   }
-  const BothGeometry both = both_from_environment();
-  Lz4CompressShape bs = {};
-  if (both.on()) {
-    bs.tagged = both.near; // (waves with their table in LDS)
-    bs.plain = both.far;
-    bs.lds_bytes = both.near * (2u * (ht_size < 8 ? 8u : ht_size) + 2u * both.slots) + both.far * 2u * both.slots;
-    if (bs.lds_bytes > kLdsPerCu)
-      return hipErrorInvalidValue;
-    set_groups(bs, batch);
-    if (both.far > 0 && (size_t)bs.groups * both.far > far_capacity)
-      bs.groups = (uint32_t)(far_capacity / both.far);
-    if (bs.groups == 0)
-      return hipErrorInvalidValue;
+  const hipError_t e = hipMemsetAsync(header, 0, kHeaderWords * sizeof(uint32_t), stream);
+  if (e != hipSuccess)
+    return e;
+  if (mode == Lz4Mode::Auto && lists) {
+    // every chunk to the shape its data calls for
+    lz4_route_kernel<<<dim3((unsigned)((batch + kRouteChunksPerGroup - 1) / kRouteChunksPerGroup)),
+                       dim3(kRouteWaves * kWave), 0, stream>>>(in_ptrs, in_bytes, (uint32_t)batch, header, lists);
+    launch_mix(header + 4 + kClassMix, lists + kClassMix * batch);
+    for (uint32_t cls = kClassDense; cls <= kClassWide; ++cls)
+      if (!launch_far(cls, header + 4 + cls, lists + cls * batch))
+        return hipErrorInvalidValue; // (cannot happen: the LDS-table waves need nothing but the header)
+    return hipSuccess;
   }
-  for (int wide = 0; wide < 2; ++wide)
-    if (mode == Lz4Mode::Auto || mode == (wide ? Lz4Mode::FarWide : Lz4Mode::Far)) {
-      if (both.on())
-        both_kernel_for(elem_size, wide != 0)<<<dim3(bs.groups), dim3(bs.waves() * kWave), bs.lds_bytes, stream>>>(
-            in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, both.near, both.slots, (uint32_t)batch, ticket,
-            chunks_per_ticket(bs), chosen);
-      else
-        far_kernel_for(elem_size, wide != 0)<<<dim3(far.groups), dim3(far.waves() * kWave), far.lds_bytes, stream>>>(
-            in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, (uint32_t)batch, ticket,
-            chunks_per_ticket(far), chosen);
-    }
+  const uint32_t forced = mode == Lz4Mode::Far ? kClassDense : mode == Lz4Mode::FarSparse ? kClassSparse
+                          : mode == Lz4Mode::FarWide ? kClassWide : kClassMix;
+  if (forced == kClassMix || !launch_far(forced, nullptr, nullptr))
+    launch_mix(nullptr, nullptr);
   return hipSuccess;
 }
 

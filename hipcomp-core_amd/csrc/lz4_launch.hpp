@@ -32,24 +32,27 @@ struct Lz4CompressShape
 // the shape with the tables in LDS
 Lz4CompressShape lz4_compress_shape_mix(uint32_t ht_size, size_t batch);
 
-enum class Lz4Mode { Auto, Mix, Far, FarWide };
-// HIPCOMP_LZ4_SHAPE = auto | mix | far | farw (read at every call; default auto).  A
-// measurement / test knob: the compressed bytes do not depend on it.
+enum class Lz4Mode { Auto, Mix, Far, FarSparse, FarWide };
+// HIPCOMP_LZ4_SHAPE = auto | mix | far | fars | farw (read at every call; default auto).  A
+// measurement / test knob: the compressed bytes do not depend on it.  auto: a routing kernel
+// puts every chunk on the list of the shape its data calls for; the others run every chunk
+// through one shape (far / fars: the lean form with the launch geometry for dense / sparse data).
 Lz4Mode lz4_mode_from_environment();
 
-// `scratch` points at four zero-initialised-by-the-launcher uint32 in device
-// memory (the head of the caller's temp buffer): the ticket counter from which
-// the waves of the persistent workgroups draw chunk numbers, and the three
-// counters of the sampling kernel that pick the shape.  nullptr = one chunk per wave,
-// as many workgroups as that takes, "mix" shape.  `far_tables`: 16-byte aligned
-// device memory for far_capacity hash tables of max(ht_size, 8) uint16 each
-// (the rest of the temp buffer), used by the "far" shape while the call runs;
-// nullptr / 0 = never that shape.  batch must be > 0 and < 2^31.
+// `temp` / `temp_bytes`: the caller's temp buffer (hipcompBatchedLZ4CompressGetTempSize bytes by
+// contract), used while the call runs as far as it goes: 16 words of header -- a chunk ticket
+// counter and a list length per launch shape, sample totals -- zeroed by the launcher on the
+// stream, the routing kernel's lists (4 x batch words), and hash tables for the far kernel's
+// device-table waves (max(ht_size, 8) uint16 each, 16-byte aligned).  Too small for the lists:
+// no routing, the LDS shape for all; too small for the header: one chunk per wave.  nullptr / 0
+// is accepted (the same).  batch must be > 0 and < 2^31.
 hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
-    size_t batch, int elem_size, uint32_t* scratch, uint16_t* far_tables, size_t far_capacity,
+    size_t batch, int elem_size, void* temp, size_t temp_bytes,
     size_t max_chunk_bytes, Lz4Mode mode, hipStream_t stream);
+// what the launcher makes use of at most (for callers that size their own scratch: hlif.hip)
+size_t lz4_compress_temp_bytes_used(uint32_t ht_size, size_t batch);
 
 // write_out == false: parse-only pass that reports sizes.
 void lz4_launch_decompress(

@@ -1,6 +1,7 @@
 """A/B of LZ4 launch shapes / geometries in ONE process on the same buffers (the knobs are read at
 every call): ab_shapes.py --chunks N --dist harness,text --dtype char CONFIG [CONFIG ...]
-CONFIG = SHAPE[:BOTH] e.g. auto  far  far:4,0,2048  auto:1,7,512 ; bytes are compared with the first config's."""
+CONFIG = SHAPE[:BOTH][@VARIANT] e.g. auto  far  far:4,0,2048  auto:1,7,512  auto:1,3,512@span52 (lib/libhipcomp_span52.so);
+bytes are compared with the first config's."""
 import argparse, importlib, os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,13 +20,24 @@ dev = torch.device("cuda:0")
 SEEDS = {"uniform": 0x5EED0002, "harness": 0x5EED0003, "runs": 0x5EED0004}
 
 
+LIBS = {}
+
+
+def lib_of(cfg):
+    variant = cfg.partition("@")[2]
+    if variant not in LIBS:
+        LIBS[variant] = hc.HipcompLibrary(os.path.join(ROOT, "hipcomp-core_amd", "lib", f"libhipcomp_{variant}.so")) if variant else hc.default_library()
+    return LIBS[variant]
+
+
 def set_config(cfg):
+    cfg = cfg.partition("@")[0]
     shape, _, both = cfg.partition(":")
     os.environ["HIPCOMP_LZ4_SHAPE"] = shape
     if both:
-        os.environ["HIPCOMP_LZ4_BOTH"] = both
+        os.environ["HIPCOMP_LZ4_GEOMETRY"] = both
     else:
-        os.environ.pop("HIPCOMP_LZ4_BOTH", None)
+        os.environ.pop("HIPCOMP_LZ4_GEOMETRY", None)
 
 
 for dist in a.dist.split(","):
@@ -41,12 +53,14 @@ for dist in a.dist.split(","):
     for dt in a.dtype.split(","):
         t = hc.hipcompType.CHAR if dt == "char" else hc.hipcompType.INT
         job = bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(t), data)
+        codecs = {c: hc.batch.Codec("LZ4", hc.LZ4Opts(t), lib=lib_of(c)) for c in a.configs}
         first = None
         times = {c: [] for c in a.configs}
         same = {}
         for r in range(a.rounds + 1):
             for cfg in a.configs:
                 set_config(cfg)
+                job.codec = codecs[cfg]
                 if r == 0:
                     job.comp.data.zero_()
                     job.comp.sizes.zero_()

@@ -35,16 +35,17 @@ def reflib(hc):
     return hc.HipcompLibrary(O.REF_LIB_PATH)
 
 
-LZ4_SHAPES = ("auto", "mix", "far", "farw")
+LZ4_SHAPES = ("auto", "mix", "far", "fars", "farw")
 
 
 @pytest.fixture(params=LZ4_SHAPES)
 def lz4_shape(request, monkeypatch):
     """Every launch shape of the LZ4 encoder in turn (HIPCOMP_LZ4_SHAPE is read at
-    every call): "auto" lets the sampling kernel pick, the others force one --
-    also on data it would never be picked for (the far shapes on chunks without
-    a match, the LDS shape and the wide form on text).  The compressed bytes
-    must not depend on it."""
+    every call): "auto" lets the routing kernel send every chunk to the shape
+    its data calls for, the others force one for all chunks -- also on data it
+    would never be picked for (the far shapes on chunks without a match, the
+    LDS shape and the wide form on text).  The compressed bytes must not depend
+    on it."""
     monkeypatch.setenv("HIPCOMP_LZ4_SHAPE", request.param)
     return request.param
 

@@ -30,6 +30,14 @@ def _want(oracle, c: bytes, es: int, max_chunk: int, **kw) -> bytes:
     return _ORACLE_CACHE[key]
 
 
+def _header(temp):
+    """the launcher's 16-word header at the head of the temp buffer (lz4_launch.hpp): ticket counters
+    and list lengths per class {mix, dense, sparse, wide}, totals of the samples"""
+    import torch
+    h = temp[:64].view(torch.int32).cpu().tolist()
+    return h[0:4], h[4:8], h[8:11]
+
+
 def _compress(hc, chunks, dtype, max_chunk, lib=None):
     import torch
     src = hc.batch.from_host_chunks(chunks, "cuda:0")
@@ -102,9 +110,9 @@ def test_sparse_matches_walk_and_rollback(hc, oracle, reflib, cuda, lz4_shape, t
 
 @pytest.mark.parametrize("tname,dtype,es", TYPES)
 def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, lz4_shape, tname, dtype, es):
-    """A batch of data that compresses: the sampling kernel calls for a "far"
-    shape (hash tables in the temp buffer or, for the waves that have one, in
-    LDS).  Checked: the counters it left in the temp buffer, and every chunk's
+    """A batch of data that compresses: the routing kernel sends nearly all of
+    it to the far shapes (hash tables in the temp buffer or, for the waves that
+    have one, in LDS).  Checked: the lists it left in the temp buffer, and every chunk's
     bytes against the oracle (48 distinct chunks, each 32 times: text, the
     harness's data, runs, sparse repeats, ragged lengths, an empty chunk, and a
     few chunks of random bytes, which take that kernel's match-less path) and
@@ -130,12 +138,17 @@ def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, lz4_s
     temp = torch.full((codec.compress_temp_size(src.n, 65536),), 0xAB, dtype=torch.uint8, device=src.device)
     assert codec.compress_async(src, 65536, temp, dst) == 0
     torch.cuda.synchronize()
-    ticket, repeats, looked = temp[:12].view(torch.int32).cpu().tolist()
-    assert ticket >= src.n
-    if lz4_shape == "auto":                                             # (a forced shape skips the sampling kernel)
-        assert looked > 0 and repeats * 4 > looked                     # the sampler's verdict: compressible
-    if lz4_shape in ("far", "farw"):
-        assert bool((temp[16 : 16 + 4 * 32768] != 0xAB).any().item())  # hash tables in the temp buffer were written
+    tickets, counts, (repeats, looked, near) = _header(temp)
+    if lz4_shape == "auto":                                             # (a forced shape skips the routing kernel)
+        assert sum(counts) == src.n and all(t >= c for t, c in zip(tickets, counts))
+        assert looked > 0 and repeats * 4 > looked                     # the samples' totals: compressible
+        assert counts[0] >= 5 * 32                                     # random bytes, the empty chunk, the tiny one: LDS shape
+        assert counts[1] + counts[2] + counts[3] >= 30 * 32            # text, the harness's data, runs: far shapes
+    else:
+        forced = {"mix": 0, "far": 1, "fars": 2, "farw": 3}[lz4_shape]
+        assert tickets[forced] >= src.n and sum(counts) == 0
+    if lz4_shape in ("far", "fars", "farw"):                           # 1536 chunks: device-table waves beside the LDS ones
+        assert bool((temp[64 + 16 * src.n:] != 0xAB).any().item())     # hash tables in the temp buffer were written
     got = dst.to_host_chunks()
     for i in range(len(chunks)):
         assert got[i] == want[i % 48], f"chunk {i} {tname} shape={lz4_shape}: kernel != oracle"
@@ -186,9 +199,10 @@ def test_most_repetitive_batches_take_the_widest_span(hc, oracle, reflib, cuda, 
     temp = torch.zeros((codec.compress_temp_size(src.n, 65536),), dtype=torch.uint8, device=src.device)
     assert codec.compress_async(src, 65536, temp, dst) == 0
     torch.cuda.synchronize()
-    ticket, repeats, looked = temp[:12].view(torch.int32).cpu().tolist()
+    tickets, counts, (repeats, looked, near) = _header(temp)
     if lz4_shape == "auto":
         assert looked > 0 and repeats * 8 > looked * 7
+        assert counts[1] >= src.n * 3 // 4                              # the dense class: widest span, all 32 waves
     got = dst.to_host_chunks()
     for i in range(len(chunks)):
         assert got[i] == want[i % len(base)], f"chunk {i} {tname} shape={lz4_shape}: kernel != oracle"

@@ -314,8 +314,9 @@ def cpu_codec_baseline(codec: str, sample, reps: int = 2):
                       f"ratio {total / max(ct.value, 1):.3f}"}
 
 
-def measure_row(hc, lib, codec: str, opts, data, label: dict, reps: int = 2):
-    """One extra row: compress / decompress of `data` through `codec`."""
+def measure_row(hc, lib, codec: str, opts, data, label: dict, key: str, reps: int = 3):
+    """One extra row: compress / decompress of `data` through `codec`.  `key` names the row in
+    profiles/r03_rows.json (the rocprof passes of the same workload)."""
     import torch
     job = CodecJob(hc, lib, codec, opts, data)
     job.compress(); job.decompress(); torch.cuda.synchronize()
@@ -323,37 +324,113 @@ def measure_row(hc, lib, codec: str, opts, data, label: dict, reps: int = 2):
     tc, td = time_phases(job, reps)
     nb, cb = job.total, job.compressed_bytes()
     row = dict(label)
-    row.update({"chunks": job.n, "ratio": nb / max(cb, 1),
+    row.update({"row": key, "chunks": job.n, "ratio": nb / max(cb, 1),
                 "compress_GBps": nb / (min(tc) * 1e-3) / 1e9, "decompress_GBps": nb / (min(td) * 1e-3) / 1e9,
                 "roundtrip_GBps": nb / ((min(tc) + min(td)) * 1e-3) / 1e9,
+                "compress_ms": min(tc), "decompress_ms": min(td),
                 "hbm_frac_compress": (nb + cb) / (min(tc) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "hbm_frac_decompress": (nb + cb) / (min(td) * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                "hbm_frac_decompress": (nb + cb) / (min(td) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "roofline": {"compress": roofline_of(key, "compress", nb + cb, min(tc)),
+                             "decompress": roofline_of(key, "decompress", nb + cb, min(td))}})
     del job
     torch.cuda.empty_cache()
     return row
 
 
+def gen_mixed(n_chunks: int, device):
+    """Chunk i: uniform data (no match at all) for even i, the harness's data for odd i -- a batch as a
+    column store hands it over: columns that do not compress beside columns that do."""
+    import torch
+    h = n_chunks // 2
+    a = gen_data("uniform", 0, h, device, 0x5EED0002).view(h, CHUNK)
+    b = gen_data("harness", 0, h, device, 0x5EED0003).view(h, CHUNK)
+    return torch.stack([a, b], dim=1).reshape(-1).contiguous()
+
+
+def measure_hlif(hc, data, reps: int = 2):
+    """the high-level LZ4 manager (container = header + offsets / sizes / checksums + chunks,
+    include/hipcomp/hlif.h) over one buffer, beside the batched calls it wraps."""
+    import torch
+    from ctypes import c_int, c_size_t, c_void_p
+    L = ctypes.CDLL(hc.default_library().path)
+    h = c_void_p()
+    assert L.hipcompHlifLZ4ManagerCreate(c_size_t(CHUNK), c_int(0), None, ctypes.byref(h)) == 0
+    n = int(data.numel())
+    mx, nc = c_size_t(0), c_size_t(0)
+    assert L.hipcompHlifConfigureCompression(h, c_size_t(n), ctypes.byref(mx), ctypes.byref(nc)) == 0
+    dst = torch.empty(mx.value + 8, dtype=torch.uint8, device=data.device)
+    back = torch.empty(n, dtype=torch.uint8, device=data.device)
+
+    def comp():
+        assert L.hipcompHlifCompress(h, c_void_p(data.data_ptr()), c_size_t(n), c_void_p(dst.data_ptr())) == 0
+
+    def dec():
+        assert L.hipcompHlifDecompress(h, c_void_p(dst.data_ptr()), c_void_p(back.data_ptr())) == 0
+    comp(); dec(); torch.cuda.synchronize()
+    st = c_int(-1)
+    assert L.hipcompHlifGetLastStatus(h, ctypes.byref(st)) == 0 and st.value == 0
+    assert bool(torch.equal(back, data)), "HLIF round trip mismatch"
+    size = c_size_t(0)
+    assert L.hipcompHlifGetCompressedSize(h, c_void_p(dst.data_ptr()), ctypes.byref(size)) == 0
+    tcs, tds = [], []
+    for _ in range(reps):       # (host wall time around a stream sync: decompress reads the header on the host)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); comp(); torch.cuda.synchronize(); tcs.append(time.perf_counter() - t0)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); dec(); torch.cuda.synchronize(); tds.append(time.perf_counter() - t0)
+    L.hipcompHlifManagerDestroy(h)
+    return {"codec": "LZ4 high-level manager (HLIF)", "row": "hlif/lz4/uniform/char", "chunks": nc.value,
+            "container_bytes": size.value, "ratio": n / max(size.value, 1),
+            "compress_GBps": n / min(tcs) / 1e9, "decompress_GBps": n / min(tds) / 1e9,
+            "compress_ms": min(tcs) * 1e3, "decompress_ms": min(tds) * 1e3,
+            "note": "host wall time incl. the stream synchronisation; slabs of <= 8192 chunks through the batched kernels, "
+                    "then a scan of the sizes and a gather into the container"}
+
+
 def kernel_source_id() -> str:
-    """Identifies the LZ4 kernel build a PMC pass belongs to."""
-    with open(os.path.join(ROOT, "hipcomp-core_amd", "csrc", "lz4_kernels.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    """Identifies the kernel build a rocprof pass belongs to: sha256 over the device sources."""
+    import glob
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hipcomp-core_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hiph")) + glob.glob(os.path.join(d, "*.hpp"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
-def pmc_traffic(dist: str, dtype: str, chunks: int):
-    """HBM-side bytes per compress launch from the committed rocprofv3 PMC passes
-    (profiles/lz4_hbm_traffic.json: FETCH_SIZE doubled as the gfx950 note in
-    MI355X_MICROARCH.md prescribes, + WRITE_SIZE).  None when there is no pass
-    for this workload OR the pass was taken on another build of the kernel
-    (the entry records the sha256 of lz4_kernels.hip it was measured on)."""
-    path = os.path.join(ROOT, "profiles", "lz4_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        table = json.load(f)
-    ent = table.get(f"{dist}/{dtype}/{chunks}")
-    if not ent or ent.get("kernel_source_sha16") != kernel_source_id():
-        return None
-    return ent.get("traffic_bytes_per_launch")
+PROFILED_ROWS = None
+
+
+def profiled(label: str, phase: str):
+    """What the committed rocprofv3 passes say about one bench row's kernel (profiles/r03_rows.json,
+    written by scripts/collect_profiles.sh + scripts/profile_rows.py): average duration from
+    --kernel-trace --stats, HBM-side bytes per launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes
+    (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE).  None when
+    there is no pass for this row OR the passes were taken on another build of the kernels (the file
+    records the sha256 of the device sources it was measured on)."""
+    global PROFILED_ROWS
+    if PROFILED_ROWS is None:
+        path = os.path.join(ROOT, "profiles", "r03_rows.json")
+        PROFILED_ROWS = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                table = json.load(f)
+            if table.get("kernel_source_sha16") == kernel_source_id():
+                PROFILED_ROWS = table.get("rows", {})
+    return PROFILED_ROWS.get(label, {}).get(phase)
+
+
+def roofline_of(label: str, phase: str, algo_bytes: int, ms: float):
+    """The roofline object of one row and phase: algorithmic bytes (N + C) over the HIP-event
+    time of the launch measured here, beside what the committed rocprof passes of the same row hold."""
+    ach = algo_bytes / (ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "algorithmic_bytes_per_launch": algo_bytes, "traffic": None}
+    p = profiled(label, phase)
+    if p:
+        r.update({"kernel": p.get("kernel"), "traffic": p.get("traffic_bytes_per_launch"),
+                  "rocprof_avg_ms": p.get("avg_ms"),
+                  "traffic_over_algorithmic": (p["traffic_bytes_per_launch"] / algo_bytes) if p.get("traffic_bytes_per_launch") else None})
+    return r
 
 
 def main():
@@ -377,6 +454,7 @@ def main():
     ap.add_argument("--no-variants", dest="variants", action="store_false",
                     help="skip the extra rows (other distributions / data types / codecs)")
     ap.add_argument("--variant-chunks", type=int, default=100000)
+    ap.add_argument("--text-chunks", type=int, default=65536, help="chunks of TPC-H-like text for the config-4 rows (4 GiB)")
     ap.add_argument("--dry-run", action="store_true",
                     help="process plumbing only (spawn, rendezvous, barrier, slice arithmetic, reductions) with no "
                          "GPU and no codec call; prints a line whose value is null -- for the CPU tests")
@@ -486,15 +564,10 @@ def main():
             "compress_GBps": n_bytes / (tc_avg * 1e-3) / 1e9,
             "decompress_GBps": n_bytes / (td_avg * 1e-3) / 1e9,
             "compress_ms": tc_avg, "decompress_ms": td_avg,
-            "roofline": {
-                "bound": "hbm", "kernel": "lz4_compress_kernel",
-                "achieved": algo / (tc_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": algo / (tc_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.dist, args.dtype, args.chunks),
-                "algorithmic_bytes_per_launch": algo,
-                "decompress_achieved": algo / (td_avg * 1e-3) / 1e9,
-                "decompress_frac": algo / (td_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            },
+            "roofline": dict(roofline_of(f"lz4/{args.dist}/{args.dtype}/{args.chunks}", "compress", algo, tc_avg),
+                             kernel="lz4_compress_kernel_mix" if args.dist == "uniform" else "lz4_compress_kernel_far",
+                             decompress_achieved=algo / (td_avg * 1e-3) / 1e9,
+                             decompress_frac=algo / (td_avg * 1e-3) / 1e9 / HBM_PEAK_GBS),
         }
         if args.ref:
             from oracle import oracle as O
@@ -534,30 +607,63 @@ def main():
     if rank == 0 and args.variants and world == 1:
         rows = []
         vc = args.variant_chunks
+        seeds = {"uniform": 0x5EED0002, "harness": 0x5EED0003, "runs": 0x5EED0004}
         for i, (dn, tn) in enumerate((("uniform", "int"), ("harness", "char"), ("harness", "int"),
                                       ("runs", "char"), ("runs", "int"))):
-            d = gen_data(dn, 0, vc, dev, {"uniform": 0x5EED0002, "harness": 0x5EED0003, "runs": 0x5EED0004}[dn])
+            d = gen_data(dn, 0, vc, dev, seeds[dn])
             t = hc.hipcompType.CHAR if tn == "char" else hc.hipcompType.INT
             rows.append(measure_row(hc, lib, "LZ4", hc.LZ4Opts(t), d,
-                                    {"codec": "LZ4", "distribution": dn, "data_type": tn.upper()}))
+                                    {"codec": "LZ4", "distribution": dn, "data_type": tn.upper()}, f"lz4/{dn}/{tn}/{vc}"))
             del d
-        text_host = gen_text(1 << 30)
+        # the headline next to its five siblings: the geometric mean of the round trips of the three
+        # distributions x {CHAR, INT} (the headline alone is the friendliest of the six)
+        six = [res["value"]] + [r["roundtrip_GBps"] for r in rows]
+        g = 1.0
+        for v in six:
+            g *= v
+        res["geomean_roundtrip_GBps"] = g ** (1.0 / len(six))
+        res["geomean_of"] = "LZ4 round trip GB/s of {uniform, harness, runs} x {CHAR, INT}, %d chunks each" % vc
+        # a batch that mixes chunks without matches and chunks that compress (the routing kernel sends every
+        # chunk to its shape): against the time-weighted sum of its halves measured alone
+        d = gen_mixed(vc, dev)
+        mrow = measure_row(hc, lib, "LZ4", hc.LZ4Opts(hc.hipcompType.CHAR), d,
+                           {"codec": "LZ4", "distribution": "mixed: chunk i uniform for even i, harness for odd i", "data_type": "CHAR"},
+                           f"lz4/mixed/char/{vc}")
+        halves = (res["compress_ms"] * vc / args.chunks + next(r for r in rows if r["row"] == f"lz4/harness/char/{vc}")["compress_ms"]) / 2
+        mrow["compress_ms_time_weighted_sum_of_halves"] = halves
+        mrow["compress_over_halves"] = mrow["compress_ms"] / halves
+        rows.append(mrow)
+        del d
+        # batches far smaller than the chip holds waves (the reference harness's own sizes): 1000 chunks
+        for dn in ("harness", "text"):
+            d = (gen_data(dn, 0, 1000, dev, seeds[dn]) if dn != "text" else torch.from_numpy(gen_text(1000 * CHUNK)).to(dev))
+            rows.append(measure_row(hc, lib, "LZ4", hc.LZ4Opts(hc.hipcompType.CHAR), d,
+                                    {"codec": "LZ4", "distribution": dn if dn != "text" else "tpch_lineitem_text",
+                                     "data_type": "CHAR", "note": "a small batch"}, f"lz4/{dn}/char/1000", reps=5))
+            del d
+        tchunks = args.text_chunks
+        text_host = gen_text(tchunks * CHUNK)
         text = torch.from_numpy(text_host).to(dev)
         rows.append(measure_row(hc, lib, "LZ4", hc.LZ4Opts(hc.hipcompType.CHAR), text,
-                                {"codec": "LZ4", "distribution": "tpch_lineitem_text", "data_type": "CHAR"}))
+                                {"codec": "LZ4", "distribution": "tpch_lineitem_text", "data_type": "CHAR"}, f"lz4/text/char/{tchunks}"))
         srow = measure_row(hc, lib, "Snappy", hc.SnappyOpts(0), text,
-                           {"codec": "Snappy", "config": "BASELINE configs[3]: TPC-H lineitem-like text, 1 GiB, 64 KiB chunks"})
+                           {"codec": "Snappy", "config": f"BASELINE configs[3]: TPC-H lineitem-like text, {tchunks} x 64 KiB chunks"},
+                           f"snappy/text/{tchunks}")
         if not args.no_cpu:
             srow["cpu_baseline"] = cpu_codec_baseline("Snappy", text_host[: 8192 * CHUNK])
         rows.append(srow)
         del text, text_host
         cols = gen_sorted_columns(vc, dev)
         crow = measure_row(hc, lib, "Cascaded", hc.CascadedOpts(4096, hc.hipcompType.UINT, 2, 1, 1), cols,
-                           {"codec": "Cascaded", "config": "BASELINE configs[2]: sorted uint32 columns, opts {4096, UINT, 2, 1, 1}"})
+                           {"codec": "Cascaded", "config": "BASELINE configs[2]: sorted uint32 columns, opts {4096, UINT, 2, 1, 1}"},
+                           f"cascaded/sorted/{vc}")
         if not args.no_cpu:
             crow["cpu_baseline"] = cpu_codec_baseline("Cascaded", cols[: 8192 * CHUNK].cpu().numpy())
         rows.append(crow)
         del cols
+        d = gen_data("uniform", 0, vc, dev, seeds["uniform"]).view(torch.uint8)
+        rows.append(measure_hlif(hc, d))
+        del d
         res["extra_keys"] = rows
     if rank == 0:
         emit(res)

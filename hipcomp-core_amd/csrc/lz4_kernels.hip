@@ -117,7 +117,8 @@ typedef void (*MixKernel)(
     const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t, uint32_t,
     uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint32_t*);
 typedef void (*FarKernel)(const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint16_t*,
-                          uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint32_t*);
+                          uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, const uint32_t*,
+                          const uint32_t*);
 
 MixKernel mix_kernel_for(int elem_size)
 {
@@ -408,14 +409,14 @@ hipError_t lz4_launch_compress(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
         (uint32_t)batch, ticket, chunks_per_ticket((size_t)mix.groups * mix.waves()), count, list);
   };
-  auto launch_far = [&](uint32_t cls, const uint32_t* count, const uint32_t* list) -> bool {
+  auto launch_far = [&](uint32_t cls, const uint32_t* counts, const uint32_t* all_lists) -> bool {
     const FarGeometry g = far_geometry(ht_size, cls, batch, far_tables ? far_capacity : 0);
     if (g.groups == 0 || g.lds_bytes > kLdsPerCu)
       return false;
     far_kernel_for(elem_size, cls == kClassWide)<<<dim3(g.groups), dim3(g.waves() * kWave), g.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, g.near, g.slots,
         cls == kClassDense ? (uint32_t)kFarSpanMost : (uint32_t)kFarSpan, (uint32_t)batch, header + cls,
-        chunks_per_ticket((size_t)g.groups * g.waves()), count, list);
+        chunks_per_ticket((size_t)g.groups * g.waves()), cls, counts, all_lists);
     return true;
   };
   if (!header) { // (a temp buffer too small for a ticket counter)
@@ -427,11 +428,16 @@ hipError_t lz4_launch_compress(
     return e;
   if (mode == Lz4Mode::Auto && lists) {
     // every chunk to the shape its data calls for
-    lz4_route_kernel<<<dim3((unsigned)((batch + kRouteChunksPerGroup - 1) / kRouteChunksPerGroup)),
-                       dim3(kRouteWaves * kWave), 0, stream>>>(in_ptrs, in_bytes, (uint32_t)batch, header, lists);
+    // (chunks per workgroup: one per wave while that leaves the chip room, at most 64 -- one list
+    // atomic per workgroup and class, and the atomics of a class all go to one address)
+    uint32_t per_group = kRouteWaves;
+    while (per_group < kRouteMostPerGroup && batch / per_group > 4096)
+      per_group *= 2;
+    lz4_route_kernel<<<dim3((unsigned)((batch + per_group - 1) / per_group)), dim3(kRouteWaves * kWave), 0, stream>>>(
+        in_ptrs, in_bytes, (uint32_t)batch, per_group, header, lists);
     launch_mix(header + 4 + kClassMix, lists + kClassMix * batch);
     for (uint32_t cls = kClassDense; cls <= kClassWide; ++cls)
-      if (!launch_far(cls, header + 4 + cls, lists + cls * batch))
+      if (!launch_far(cls, header + 4, lists))
         return hipErrorInvalidValue; // (cannot happen: the LDS-table waves need nothing but the header)
     return hipSuccess;
   }

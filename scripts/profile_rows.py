@@ -1,0 +1,73 @@
+"""profiles/rNN_rows.json from the rocprofv3 passes of scripts/collect_profiles.sh.
+
+usage: profile_rows.py <dir with stats_<K>/ fetch_<K>/ write_<K>/ per row> <json out> <row>=<K> [...]
+Per row and phase (compress / decompress): the kernel that did the work (the one with the largest
+total time whose name holds the phase), its average duration over the dispatches that did work --
+with per-chunk routing a compress call launches one kernel per class and the ones whose list is
+empty leave at once: dispatches shorter than a tenth of the longest are left out, here and in the
+PMC averages -- and the HBM-side bytes per launch from the separate --pmc FETCH_SIZE / WRITE_SIZE
+passes: traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE tallies 128-byte requests
+at 64 bytes for wide streaming reads, MI355X_MICROARCH.md; narrower gathers are not calibrated, so the
+read side is an upper estimate).  The file records the sha256 of the device sources (bench.kernel_source_id):
+bench.py ignores it for any other build."""
+import csv, glob, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    m = re.search(r"(\w+_kernel\w*)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
+
+
+def trace_durations(d):
+    """kernel name -> list of dispatch durations (ns) from the kernel trace"""
+    out = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            out.setdefault(short(r["Kernel_Name"]), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return out
+
+
+def counter(d, name):
+    out = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == name:
+                out.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+    return out
+
+
+def working(values):
+    top = max(values)
+    return [v for v in values if v * 10 >= top]
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    import bench
+    table = {"_how": __doc__.split("\n\n", 1)[1].strip(), "kernel_source_sha16": bench.kernel_source_id(), "rows": {}}
+    for spec in sys.argv[3:]:
+        row, k = spec.split("=")
+        dur = trace_durations(os.path.join(src, "stats_" + k))
+        fetch, write = counter(os.path.join(src, "fetch_" + k), "FETCH_SIZE"), counter(os.path.join(src, "write_" + k), "WRITE_SIZE")
+        ent = {}
+        for phase in ("compress", "decompress"):
+            names = [n for n in dur if phase in n and (phase != "compress" or "decompress" not in n)]
+            if not names:
+                continue
+            kn = max(names, key=lambda n: sum(dur[n]))
+            w = working(dur[kn])
+            e = {"kernel": kn, "avg_ms": sum(w) / len(w) / 1e6, "dispatches": len(w), "dispatches_left_out": len(dur[kn]) - len(w)}
+            if kn in fetch and kn in write:
+                fw, ww = working(fetch[kn]), working(write[kn])
+                e.update({"FETCH_SIZE_KiB": sum(fw) / len(fw), "WRITE_SIZE_KiB": sum(ww) / len(ww),
+                          "traffic_bytes_per_launch": (2 * sum(fw) / len(fw) + sum(ww) / len(ww)) * 1024})
+            ent[phase] = e
+        table["rows"][row] = ent
+    json.dump(table, open(dst, "w"), indent=1)
+    print(json.dumps(table["rows"], indent=1))
+
+
+main()

@@ -140,7 +140,7 @@ def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, lz4_s
     torch.cuda.synchronize()
     tickets, counts, (repeats, looked, near) = _header(temp)
     if lz4_shape == "auto":                                             # (a forced shape skips the routing kernel)
-        assert sum(counts) == src.n and all(t >= c for t, c in zip(tickets, counts))
+        assert sum(counts) == src.n and tickets[0] >= counts[0] and sum(tickets[1:]) >= sum(counts[1:])
         assert looked > 0 and repeats * 4 > looked                     # the samples' totals: compressible
         assert counts[0] >= 5 * 32                                     # random bytes, the empty chunk, the tiny one: LDS shape
         assert counts[1] + counts[2] + counts[3] >= 30 * 32            # text, the harness's data, runs: far shapes

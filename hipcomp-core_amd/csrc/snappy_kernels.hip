@@ -575,7 +575,7 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
   // literal << 16 | 1-byte-offset copy << 17 | not for the fast path << 31
   // (4-byte offset, literal with a length field).
   __shared__ uint32_t tag_lut[256];
-  __shared__ uint8_t rank_to_lane[kDecompWavesPerBlock][kWave]; // (the several-elements step below)
+  __shared__ uint16_t start_of_output[kDecompWavesPerBlock][kWave]; // (the several-elements step below)
   static_assert(kWave * kDecompWavesPerBlock == 256, "one tag per thread");
   {
     const uint32_t b = threadIdx.x, kind = b & 3u, n6 = b >> 2;
@@ -653,31 +653,72 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
             const uint32_t ib = vcur - sw.base;
             const uint32_t w_here = sw.bytes_at(ib + i);
             const uint32_t e_here = tag_lut[w_here & 0xFFu];
-            // need | output bytes << 8 | of this path's kinds << 16
-            const uint32_t says = ((e_here >> 8) & 0xFFu) | ((e_here & 0xFFu) << 8) | ((e_here >> 31) ? 0u : 1u << 16);
             const uint32_t avail_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)avail);
             const uint32_t room = min((uint32_t)__builtin_amdgcn_readfirstlane((int)vleft), (uint32_t)kWave);
-            uint32_t at = 0, total = 0, count = 0;
-            uint64_t stream_starts = 0, out_starts = 0;
-            uint32_t p = read_lane(says, 0);
-            while ((p >> 16) != 0 && total + ((p >> 8) & 0xFFu) <= room && at + (p & 0xFFu) <= avail_s) {
-              asm("s_bitset1_b64 %0, %1" : "+s"(stream_starts) : "s"(at));
-              asm("s_bitset1_b64 %0, %1" : "+s"(out_starts) : "s"(total));
-              total += (p >> 8) & 0xFFu;
-              at += p & 0xFFu;
-              ++count;
-              p = at < (uint32_t)kWave ? read_lane(says, (int)(at & 63u)) : 0u;
+            // What a lane says about the element that would start at its stream byte: stream bytes |
+            // output bytes << 8 if it is one this step takes -- of this path's kinds, all of it inside
+            // the stream -- else a word that ends the walk.
+            const uint32_t need_here = (e_here >> 8) & 0xFFu, ob_here = e_here & 0xFFu;
+            const uint32_t says = ((e_here >> 31) == 0u && i + need_here <= avail_s) ? (need_here | (ob_here << 8)) : 0x10000u;
+            // The walk from element to element is all the scalar unit does for an element (as in the
+            // LZ4 decoder, lz4_decode.hiph: the step was bound by its scalar instructions): stream
+            // position (low byte) and output bytes (above it) move on with ONE add, the word that ends
+            // the walk and an output that no longer fits fail the same compare, the position past lane
+            // 63 is one masked test; written out, unrolled once (the compiler's loop: eleven scalar
+            // instructions and five branches per element).
+            uint64_t stream_starts;
+            uint32_t acc;
+            {
+              const uint32_t limit = uniform((room << 8) | 0xFFu);
+              uint32_t nxt, p, tmp;
+              asm volatile("s_mov_b64 %[starts], 0\n\t"
+                           "s_mov_b32 %[acc], 0\n\t"
+                           "v_readlane_b32 %[p], %[says], 0\n"
+                           "1:\n\t"
+                           "s_add_u32 %[nxt], %[acc], %[p]\n\t"
+                           "s_cmp_gt_u32 %[nxt], %[limit]\n\t"
+                           "s_cbranch_scc1 2f\n\t"            // the element at acc is not taken: acc stands
+                           "s_bitset1_b64 %[starts], %[acc]\n\t" // (bit acc[5:0] = its stream position)
+                           "s_and_b32 %[tmp], %[nxt], 0xc0\n\t"
+                           "s_cbranch_scc1 3f\n\t"            // the next element lies beyond the 64 lanes
+                           "v_readlane_b32 %[p], %[says], %[nxt]\n\t"
+                           "s_add_u32 %[acc], %[nxt], %[p]\n\t"
+                           "s_cmp_gt_u32 %[acc], %[limit]\n\t"
+                           "s_cbranch_scc1 3f\n\t"            // the element at nxt is not taken
+                           "s_bitset1_b64 %[starts], %[nxt]\n\t"
+                           "s_and_b32 %[tmp], %[acc], 0xc0\n\t"
+                           "s_cbranch_scc1 2f\n\t"
+                           "v_readlane_b32 %[p], %[says], %[acc]\n\t"
+                           "s_branch 1b\n"
+                           "3:\n\t"
+                           "s_mov_b32 %[acc], %[nxt]\n"
+                           "2:"
+                           : [starts] "=&s"(stream_starts), [acc] "=&s"(acc), [nxt] "=&s"(nxt), [p] "=&s"(p), [tmp] "=&s"(tmp)
+                           : [says] "v"(says), [limit] "s"(limit)
+                           : "scc");
             }
-            if (count >= 2) {
+            uint32_t at = acc & 0xFFu, total = acc >> 8;
+            if (__builtin_popcountll(stream_starts) >= 2) {
+              // Every output byte finds its element on the vector side: the lanes where the taken
+              // elements start know where their output starts (a prefix sum of the output bytes over
+              // those lanes) and post that and their own number at the output lane in question (a
+              // 64-entry table in LDS, cleared first: a one-byte literal may start at any lane); a
+              // running maximum hands every output lane the latest start at or below it.
               const int wave_in_block = (int)(threadIdx.x >> 6);
-              if ((stream_starts >> i) & 1ull)
-                rank_to_lane[wave_in_block][lanes_set_below(stream_starts)] = (uint8_t)i;
+              const bool on = ((stream_starts >> i) & 1ull) != 0;
+              const uint32_t ob = on ? ob_here : 0u;
+              const uint32_t o_start = wave_scan_add_u32(ob) - ob;
               lds_lane_exchange_fence();
-              const uint64_t upto = out_starts & ((2ull << i) - 1ull);
-              const uint32_t o_mine = 63u - (uint32_t)__builtin_clzll(upto | 1ull); // where my element's output starts
-              const uint32_t rank = lanes_set_below(out_starts) + (uint32_t)((out_starts >> i) & 1ull) - 1u;
-              const uint32_t t_mine = rank_to_lane[wave_in_block][rank & 63u];        // its stream lane
+              start_of_output[wave_in_block][i] = 0;
               lds_lane_exchange_fence();
+              if (on)
+                start_of_output[wave_in_block][o_start & 63u] = (uint16_t)(((o_start << 6) | i) + 1u);
+              lds_lane_exchange_fence();
+              const uint32_t got = start_of_output[wave_in_block][i];
+              lds_lane_exchange_fence();
+              const uint32_t latest = wave_scan_max_u32(got) - 1u;
+              const uint32_t o_mine = (latest >> 6) & 63u; // where my element's output starts
+              const uint32_t t_mine = latest & 63u;        // its stream lane
               const uint32_t w_mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t_mine * 4u), (int)w_here);
               const uint32_t e_mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t_mine * 4u), (int)e_here);
               const bool lit_mine = (e_mine & (1u << 16)) != 0u;

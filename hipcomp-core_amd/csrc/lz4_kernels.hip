@@ -182,7 +182,11 @@ void set_groups(Lz4CompressShape& sh, size_t batch)
 Lz4CompressShape lz4_compress_shape_mix(uint32_t ht_size, size_t batch)
 {
   Lz4CompressShape sh;
+#ifdef HC_TAG_HALF
+  sh.stride_tagged = round_up(ht_size * 2u + ht_size / 2u, 16u);
+#else
   sh.stride_tagged = round_up(ht_size * 3u, 16u);
+#endif
   sh.stride_plain = round_up(ht_size * 2u, 16u);
   // most waves per CU first (workgroups of g waves, as many as fit), then
   // most of them with tags

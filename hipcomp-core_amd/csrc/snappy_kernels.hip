@@ -234,8 +234,8 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         return clash == 0 ? read_lane(word_of_lane, t) : 0u;
       };
       // What follows a hit lane's element, for all lanes at once: bits 0-6 where
-      // the next element's window starts, 7-13 its hit lane (the first event at
-      // or above that; 127: none), bit 14: that next element is one the loop can
+      // the next element's window starts, 8-14 its hit lane (the first event at
+      // or above that; 127: none), bit 31: that next element is one the loop can
       // take without looking -- a short match, and no lane from its start to its
       // hit has a higher lane with its hash (so none of its lanes can clash with
       // anything).  While that holds an element costs the loop one v_readlane.
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         const uint32_t next_word = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((next_hit & 63u) * 4u), (int)word_of_lane);
         easy = next_hit < 64u && (next_word >> 30) == 1u && next_sharing > next_hit;
       }
-      uint32_t follows = after | (next_hit << 7) | (easy ? 1u << 14 : 0u);
+      uint32_t follows = after | (next_hit << 8) | (easy ? 1u << 31 : 0u);
       uint32_t about = pick();
       while ((about >> 30) == 1u) {
         asm("s_bitset1_b64 %0, %1" : "+s"(hit_lanes) : "s"(t));
@@ -263,16 +263,30 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         if (touched != 0) {
           // lanes with the hash of one just taken are no longer easy to pass
           stale |= touched;
-          follows = after | (next_hit << 7) | ((easy && first_at_or_above(stale) > next_hit) ? 1u << 14 : 0u);
+          follows = after | (next_hit << 8) | ((easy && first_at_or_above(stale) > next_hit) ? 1u << 31 : 0u);
         }
-        uint32_t then = read_lane(follows, t);
-        start = then & 127u; // (= t + 4 + copy length - 4)
-        while ((then & (1u << 14)) != 0) {
-          t = (int)((then >> 7) & 127u);
-          asm("s_bitset1_b64 %0, %1" : "+s"(hit_lanes) : "s"(t));
-          asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
-          then = read_lane(follows, t);
-          start = then & 127u;
+        // The elements that can be taken without a look, one after the other: four scalar
+        // instructions each (as in the LZ4 encoder, lz4_far.hiph).  `then` = what follows the hit
+        // lane t; while its sign says "easy": the next element starts at then[5:0] and hits at the
+        // lane in bits 8-13 -- s_bitset1_b64 and v_readlane look at the low six bits of their index only.
+        {
+          uint32_t then, tx = (uint32_t)t;
+          asm volatile("v_readlane_b32 %[then], %[follows], %[t]\n\t"
+                       "s_cmp_lt_i32 %[then], 0\n\t"
+                       "s_cbranch_scc0 2f\n"
+                       "1:\n\t"
+                       "s_lshr_b32 %[t], %[then], 8\n\t"
+                       "s_bitset1_b64 %[starts], %[then]\n\t"
+                       "s_bitset1_b64 %[hits], %[t]\n\t"
+                       "v_readlane_b32 %[then], %[follows], %[t]\n\t"
+                       "s_cmp_lt_i32 %[then], 0\n\t"
+                       "s_cbranch_scc1 1b\n"
+                       "2:"
+                       : [then] "=&s"(then), [t] "+s"(tx), [starts] "+s"(start_lanes), [hits] "+s"(hit_lanes)
+                       : [follows] "v"(follows)
+                       : "scc");
+          t = (int)(tx & 63u);
+          start = then & 127u; // (= t + 4 + copy length - 4)
         }
         about = pick();
       }

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Collects the profiles of one round on the GPU box (run through gpurun from the repo root):
 #   scripts/collect_profiles.sh r03 [part]      part = headline | rows | pmc | all (default)
+#   (ROWS="..." PARTNAME=rowsA: a subset of the rows into $O/${R}_rowsA.json -- a gpurun call is
+#   limited to 20 minutes; scripts/merge_rows.py joins the parts)
 # headline: rocprofv3 --kernel-trace --stats of the default bench command.
 # rows:     per bench row (bench.py extra_keys[].row) kernel trace + stats, and the HBM-side traffic from
 #           separate --pmc FETCH_SIZE / WRITE_SIZE passes -> profiles-ready $O/${R}_rows.json
@@ -15,12 +17,13 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 if [ $PART = headline ] || [ $PART = all ]; then
   rm -rf $O/stats
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 2 --no-variants --no-cpu > $O/${R}_bench_under_rocprof.json.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 2 --no-variants --no-cpu > $O/${R}_bench_under_rocprof.json.log 2> $O/bench_under_rocprof.err
   python3 scripts/summarize_profile.py $O/stats $O/${R}_lz4_uniform_char_kernel_stats.csv > /dev/null
-  tail -c 600 $O/${R}_bench_under_rocprof.json.log
+  tail -c 900 $O/${R}_bench_under_rocprof.json.log
 fi
 if [ $PART = rows ] || [ $PART = all ]; then
-  ROWS="lz4/uniform/char/100000 lz4/uniform/int/100000 lz4/harness/char/100000 lz4/harness/int/100000 lz4/runs/char/100000 lz4/runs/int/100000 lz4/mixed/char/100000 lz4/text/char/65536 lz4/harness/char/1000 lz4/text/char/1000 snappy/text/65536 cascaded/sorted/100000"
+  ROWS=${ROWS:-"lz4/uniform/char/100000 lz4/uniform/int/100000 lz4/harness/char/100000 lz4/harness/int/100000 lz4/runs/char/100000 lz4/runs/int/100000 lz4/mixed/char/100000 lz4/text/char/65536 lz4/harness/char/1000 lz4/text/char/1000 snappy/text/65536 cascaded/sorted/100000"}
+  PARTNAME=${PARTNAME:-rows}
   SPECS=""
   for ROW in $ROWS; do
     K=$(echo $ROW | tr / _)
@@ -32,7 +35,7 @@ if [ $PART = rows ] || [ $PART = all ]; then
     grep -h "^$ROW" $O/stats_$K.log || true
     SPECS="$SPECS $ROW=$K"
   done
-  python3 scripts/profile_rows.py $O $O/${R}_rows.json $SPECS > $O/rows.log 2>&1 || { cat $O/rows.log; exit 1; }
+  python3 scripts/profile_rows.py $O $O/${R}_${PARTNAME}.json $SPECS > $O/rows.log 2>&1 || { cat $O/rows.log; exit 1; }
   # (the per-dispatch csv files are large: keep the summaries)
   for ROW in $ROWS; do K=$(echo $ROW | tr / _); rm -rf $O/stats_$K $O/fetch_$K $O/write_$K; done
   tail -n 40 $O/rows.log

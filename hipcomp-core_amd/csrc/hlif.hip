@@ -276,9 +276,11 @@ struct Core
   void finish_init(size_t max_compressed_chunk)
   {
     slot_bytes = (max_compressed_chunk + 15) & ~size_t(15);
-    // a slab: about 512 MiB of slots, 256 .. 8192 chunks
-    const size_t n = (size_t(512) << 20) / slot_bytes;
-    slab = (uint32_t)(n < 256 ? 256 : (n > 8192 ? 8192 : n));
+    // a slab: about 2 GiB of slots, 256 .. 32768 chunks
+    // (every slab ends with the tail of its slowest chunk and a scan + gather of its own: large slabs --
+    // 2 GiB of slots, a small part of this card's 288 GB; the reference's scheme has no slabs at all)
+    const size_t n = (size_t(2048) << 20) / slot_bytes;
+    slab = (uint32_t)(n < 256 ? 256 : (n > 32768 ? 32768 : n));
   }
 
   Layout layout(size_t n) const { return layout_of(n, format_header_bytes); }

@@ -171,14 +171,14 @@ def test_hostile_container_headers_are_refused(hc, cuda):
 
 def test_many_chunks_take_several_slabs(hc, cuda):
     L = _lib(hc)
-    m = Manager(L, 1024, 0)                                   # slab = 8192 chunks: 20000 chunks = 3 passes
-    data = datagen.text_like(9, 20000 * 1024 - 100)
+    m = Manager(L, 1024, 0)                                   # slab = 32768 chunks: 70000 chunks = 3 passes
+    data = (datagen.text_like(9, (1 << 20) + 13) * 70)[: 70000 * 1024 - 100]
     cont, nc = m.compress(data, cuda)
-    assert nc == 20000
+    assert nc == 70000
     st, back = m.decompress(cont, cuda)
     assert st == 0 and back == data
     need = c_size_t(0)
-    assert L.hipcompHlifGetRequiredScratchBytes(m.h, ctypes.byref(need)) == 0 and need.value > 8192 * 1024
+    assert L.hipcompHlifGetRequiredScratchBytes(m.h, ctypes.byref(need)) == 0 and need.value > 32768 * 1024
     m.close()
 
 

@@ -498,3 +498,33 @@ def test_cpu_interop_example(cuda):
             pytest.skip("no liblz4 on this box")
         assert r.returncode == 0, r.stdout + r.stderr
         assert r.stdout.count("OK") == 3
+
+
+def test_small_far_classes_go_with_the_largest(hc, oracle, reflib, cuda, monkeypatch):
+    """Routing: a far-type class with fewer than 2048 chunks that is not the largest gets no launch
+    of its own (each launch ends with the tail of its slowest chunk); its chunks are worked off by
+    the largest class's kernel.  3000 chunks of the harness's data with a few chunks of run-length
+    data and of text among them: three lists, ONE ticket counter in use, every byte as the oracle's."""
+    import torch
+    monkeypatch.setenv("HIPCOMP_LZ4_SHAPE", "auto")
+    base = [datagen.harness_like_int32(900 + k, 16384).tobytes() for k in range(8)]
+    runs = [datagen.runs_of_elements(950 + k, 65536, 4, 12) for k in range(5)]
+    text = [datagen.text_like(960 + k, 65536) for k in range(3)]
+    chunks = [base[i % 8] for i in range(3000)]
+    for j, c in enumerate(runs + text):
+        chunks[137 + 311 * j] = c
+    src = hc.batch.from_host_chunks(chunks, "cuda:0")
+    codec = hc.batch.Codec("LZ4", hc.LZ4Opts(0))
+    dst = hc.batch.alloc_batch(src.n, codec.max_output_chunk_size(65536), src.device)
+    temp = torch.zeros((codec.compress_temp_size(src.n, 65536),), dtype=torch.uint8, device=src.device)
+    assert codec.compress_async(src, 65536, temp, dst) == 0
+    torch.cuda.synchronize()
+    tickets, counts, _ = _header(temp)
+    assert sum(counts) == 3000 and counts[0] == 0
+    assert counts[1] >= 2900 and counts[3] >= 3 and counts[1] + counts[2] + counts[3] == 3000
+    assert tickets[1] >= 3000 and tickets[2] == 0 and tickets[3] == 0      # one launch took all three lists
+    got = dst.to_host_chunks()
+    want = {id(c): _want(oracle, c, 1, 65536) for c in base + runs + text}
+    for i, c in enumerate(chunks):
+        assert got[i] == want[id(c)], i
+    _round_trip(hc, dst, chunks, 0)

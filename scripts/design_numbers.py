@@ -1,0 +1,49 @@
+"""The table of DESIGN.md section 9 from a bench line and the per-row rocprof summary:
+   design_numbers.py profiles/r03_bench_all_configs.json.log profiles/r03_rows.json"""
+import json, sys
+bench = None
+for ln in open(sys.argv[1]):
+    ln = ln.strip()
+    if ln.startswith("{") and '"metric"' in ln:
+        bench = json.loads(ln)
+rows = json.load(open(sys.argv[2]))
+assert bench is not None
+R = rows["rows"]
+out = []
+out.append(f"Headline (`value`): LZ4 round trip, 100 000 x 64 KiB uniform int32 as CHAR: **{bench['value']:.0f} GB/s** "
+           f"(compress {bench['compress_ms']:.2f} ms = {bench['compress_GBps']:.0f} GB/s, decompress {bench['decompress_ms']:.2f} ms = "
+           f"{bench['decompress_GBps']:.0f} GB/s); `roofline.frac` = {bench['roofline']['frac']:.3f} (compress), "
+           f"{bench['roofline']['decompress_frac']:.2f} (decompress); geometric mean of the round trips of "
+           f"{{uniform, harness, runs}} x {{CHAR, INT}}: **{bench['geomean_roundtrip_GBps']:.0f} GB/s**. "
+           f"CPU baseline in the same run: {bench.get('cpu_baseline', {}).get('value', float('nan')):.1f} GB/s round trip "
+           f"(liblz4, {bench.get('cpu_baseline', {}).get('cores', '?')} host threads).")
+out.append("")
+out.append("| row (bench `extra_keys[].row`) | ratio | compress GB/s | frac | decompress GB/s | frac | compress kernel: rocprof avg ms, HBM-side traffic / algorithmic |")
+out.append("|---|---|---|---|---|---|---|")
+
+
+def prof(key):
+    e = R.get(key, {}).get("compress")
+    if not e:
+        return "-"
+    return f"`{e['kernel']}` {e['avg_ms']:.2f} ms"
+
+
+head_key = "lz4/uniform/char/100000"
+algo = bench["roofline"]["algorithmic_bytes_per_launch"]
+e = R.get(head_key, {}).get("compress", {})
+tr = e.get("traffic_bytes_per_launch")
+out.append(f"| `{head_key}` (headline) | {bench['ratio']:.3f} | {bench['compress_GBps']:.0f} | {bench['roofline']['frac']:.3f} | "
+           f"{bench['decompress_GBps']:.0f} | {bench['roofline']['decompress_frac']:.3f} | {prof(head_key)}"
+           + (f", {tr / algo:.2f} x" if tr else "") + " |")
+for r in bench["extra_keys"]:
+    key = r.get("row", "?")
+    if "roofline" not in r:
+        out.append(f"| `{key}` | {r['ratio']:.3f} | {r['compress_GBps']:.0f} | - | {r['decompress_GBps']:.0f} | - | (host wall time; see section 7) |")
+        continue
+    rc = r["roofline"]["compress"]
+    e = R.get(key, {}).get("compress", {})
+    t = e["traffic_bytes_per_launch"] / rc["algorithmic_bytes_per_launch"] if e.get("traffic_bytes_per_launch") else None
+    out.append(f"| `{key}` | {r['ratio']:.3f} | {r['compress_GBps']:.1f} | {r['hbm_frac_compress']:.3f} | {r['decompress_GBps']:.1f} | "
+               f"{r['hbm_frac_decompress']:.3f} | {prof(key)}" + (f", {t:.2f} x" if t else "") + " |")
+print("\n".join(out))

@@ -24,13 +24,24 @@ LIBS = {}
 
 
 def lib_of(cfg):
-    variant = cfg.partition("@")[2]
+    variant = cfg.split("+")[0].partition("@")[2]
     if variant not in LIBS:
         LIBS[variant] = hc.HipcompLibrary(os.path.join(ROOT, "hipcomp-core_amd", "lib", f"libhipcomp_{variant}.so")) if variant else hc.default_library()
     return LIBS[variant]
 
 
+EXTRA_KEYS = set()
+
+
 def set_config(cfg):
+    # SHAPE[:GEOMETRY][@VARIANT][+KEY=VALUE ...]  (the +KEY=VALUE parts: environment knobs for this config only)
+    cfg, *extras = cfg.split("+")
+    for k in EXTRA_KEYS:
+        os.environ.pop(k, None)
+    for e in extras:
+        k, _, v = e.partition("=")
+        EXTRA_KEYS.add(k)
+        os.environ[k] = v
     cfg = cfg.partition("@")[0]
     shape, _, both = cfg.partition(":")
     os.environ["HIPCOMP_LZ4_SHAPE"] = shape

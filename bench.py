@@ -385,15 +385,29 @@ def measure_hlif(hc, data, reps: int = 2):
                     "then a scan of the sizes and a gather into the container"}
 
 
-def kernel_source_id() -> str:
-    """Identifies the kernel build a rocprof pass belongs to: sha256 over the device sources."""
+def _code_only(text: bytes) -> bytes:
+    """C / C++ source without comments and with white space collapsed."""
+    import re
+    t = text.decode("utf-8", "replace")
+    t = re.sub(r"/\*.*?\*/", " ", t, flags=re.S)
+    t = re.sub(r"//[^\n]*", " ", t)
+    return re.sub(r"\s+", " ", t).encode()
+
+
+def kernel_source_id(read=None) -> str:
+    """Identifies the kernel build a rocprof pass belongs to: sha256 over the device sources, comments
+    and white space left out (a reworded comment does not orphan the committed profiles).
+    `read(path) -> bytes`: another way to get at the files (scripts/rekey_rows.py reads a commit)."""
     import glob
     h = hashlib.sha256()
     d = os.path.join(ROOT, "hipcomp-core_amd", "csrc")
+    if read is None:
+        def read(path):
+            with open(path, "rb") as f:
+                return f.read()
     for path in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hiph")) + glob.glob(os.path.join(d, "*.hpp"))):
         h.update(os.path.basename(path).encode())
-        with open(path, "rb") as f:
-            h.update(f.read())
+        h.update(_code_only(read(path)))
     return h.hexdigest()[:16]
 
 

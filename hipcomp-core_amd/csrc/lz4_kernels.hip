@@ -265,6 +265,17 @@ bool geometry_from_environment(uint32_t& near, uint32_t& far, uint32_t& slots)
   return false;
 }
 
+// lanes a trip of the device-table waves' lean form looks up (HIPCOMP_LZ4_SPAN: measurement knob)
+uint32_t far_span(uint32_t cls)
+{
+  if (const char* e = std::getenv("HIPCOMP_LZ4_SPAN")) {
+    const int v = std::atoi(e);
+    if (v >= 8 && v <= 64)
+      return (uint32_t)v;
+  }
+  return cls == kClassDense ? (uint32_t)kFarSpanFull : (uint32_t)kFarSpan;
+}
+
 uint32_t groups_per_cu(uint32_t lds_bytes, uint32_t waves)
 {
   uint32_t g = kLdsPerCu / round_up(lds_bytes ? lds_bytes : 1u, kLdsGranule);
@@ -420,7 +431,7 @@ hipError_t lz4_launch_compress(
       return false;
     far_kernel_for(elem_size, cls == kClassWide)<<<dim3(g.groups), dim3(g.waves() * kWave), g.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, g.near, g.slots,
-        cls == kClassDense ? (uint32_t)kFarSpanMost : (uint32_t)kFarSpan, (uint32_t)batch, header + cls,
+        far_span(cls), (uint32_t)batch, header + cls,
         chunks_per_ticket((size_t)g.groups * g.waves()), cls, counts, all_lists);
     return true;
   };

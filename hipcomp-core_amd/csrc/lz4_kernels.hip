@@ -311,28 +311,38 @@ FarGeometry far_geometry(uint32_t ht_size, uint32_t cls, size_t batch, size_t fa
       g.groups = (uint32_t)batch;
       return g;
     }
-    // else: workgroups of one LDS-table wave and as many device-table waves as fill the CU's 32
-    // wave slots (dense, wide) or three (sparse), as many workgroups per CU as LDS holds
+    // else: workgroups of 1, 2 or 4 LDS-table waves and as many device-table waves as fill the CU's
+    // 32 wave slots (dense, wide) or three per LDS-table wave (sparse), as many workgroups per CU as
+    // LDS holds -- the split with the most LDS-table waves per CU, then the smallest workgroups
+    // (64 KiB chunks: 4 x (1 + 7); 8 KiB chunks: 8 x (1 + 3); chunks of 2 KiB: 8 x (4 + 0))
     g.slots = 512;
-    g.near = 1;
-    uint32_t best = 0;
-    for (uint32_t per_cu = 8; per_cu >= 1; --per_cu) {
-      const uint32_t nf = 32 / per_cu - 1;
-      const uint32_t lds = table + (1 + nf) * 2u * g.slots;
-      if (lds <= kLdsPerCu && kLdsPerCu / round_up(lds, kLdsGranule) >= per_cu) {
-        best = per_cu;
-        g.far = nf;
-        break;
+    uint32_t best = 0, best_near = 0;
+    for (uint32_t wn = 1; wn <= 4; wn *= 2)
+      for (uint32_t per_cu = 8; per_cu >= 1; --per_cu) {
+        if (per_cu * wn > 32)
+          continue;
+        const uint32_t nf = 32 / per_cu - wn;
+        if (wn + nf > (uint32_t)kFarMaxWavesPerGroup)
+          continue;
+        const uint32_t lds = wn * table + (wn + nf) * 2u * g.slots;
+        if (lds <= kLdsPerCu && kLdsPerCu / round_up(lds, kLdsGranule) >= per_cu) {
+          if (per_cu * wn > best_near) {
+            best_near = per_cu * wn;
+            best = per_cu;
+            g.near = wn;
+            g.far = nf;
+          }
+          break; // (fewer workgroups of this kind per CU hold no more LDS tables)
+        }
       }
-    }
     if (best == 0) { // (tables beyond what LDS holds: device-table waves only)
       g.near = 0;
       g.far = 4;
       g.slots = kFarScratchSlots;
       best = 8;
     }
-    if (cls == kClassSparse && g.near > 0 && g.far > 3)
-      g.far = 3;
+    if (cls == kClassSparse && g.near > 0 && g.far > 3 * g.near)
+      g.far = 3 * g.near;
     g.groups = best * cus;
   }
   // no more device-table waves than the batch needs and the temp buffer has tables for

@@ -528,3 +528,34 @@ def test_small_far_classes_go_with_the_largest(hc, oracle, reflib, cuda, monkeyp
     for i, c in enumerate(chunks):
         assert got[i] == want[id(c)], i
     _round_trip(hc, dst, chunks, 0)
+
+
+@pytest.mark.parametrize("tname,dtype,es", TYPES)
+def test_lean_form_near_the_end_of_a_chunk(hc, oracle, reflib, cuda, lz4_shape, tname, dtype, es):
+    """The far shapes' lean form works on windows that lie kFarLeanMargin elements or more in front of
+    the chunk's end and leaves the rest to the one-window code: chunks of every length around that
+    margin (and around the wide form's), of data whose sequences run right up to the end, so that
+    the hand-over happens at every distance from the end -- each chunk against the oracle and the
+    reference build, then the round trip."""
+    rng = np.random.default_rng(77)
+    chunks = []
+    for k, n in enumerate(range(130 * es, 900 * es, 7 * es)):
+        kind = k % 4
+        if kind == 0:
+            c = datagen.harness_like_int32(1000 + k, (n + 3) // 4 + 1).tobytes()[:n]
+        elif kind == 1:
+            c = datagen.text_like(1000 + k, n)
+        elif kind == 2:
+            c = datagen.periodic_bytes(1000 + k, n, 3 + k % 9, 40 + k % 17)
+        else:
+            c = datagen.runs_of_elements(1000 + k, n // es * es, es, 9)
+        chunks.append(c[: len(c) // es * es])
+    chunks = chunks * 12      # (more chunks than the LDS-table waves of a launch: device-table waves as well)
+    base = chunks[: len(chunks) // 12]
+    want = [_want(oracle, c, es, 65536) for c in base]
+    src, mine = _compress(hc, chunks, dtype, 65536)
+    got = mine.to_host_chunks()
+    for i in range(len(chunks)):
+        assert got[i] == want[i % len(base)], f"chunk {i} ({len(chunks[i])} bytes) {tname} shape={lz4_shape}: kernel != oracle"
+    _round_trip(hc, mine, chunks, dtype)
+    compare_with_reference(reflib, "chunks around the lean form's margin", _reference_agrees(hc, base, dtype, 65536, want, tname))

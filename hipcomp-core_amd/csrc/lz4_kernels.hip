@@ -312,9 +312,9 @@ FarGeometry far_geometry(uint32_t ht_size, uint32_t cls, size_t batch, size_t fa
       return g;
     }
     // else: workgroups of 1, 2 or 4 LDS-table waves and as many device-table waves as fill the CU's
-    // 32 wave slots (dense, wide) or three per LDS-table wave (sparse), as many workgroups per CU as
+    // 32 wave slots (dense, wide) or two and a half per LDS-table wave (sparse), as many workgroups per CU as
     // LDS holds -- the split with the most LDS-table waves per CU, then the smallest workgroups
-    // (64 KiB chunks: 4 x (1 + 7); 8 KiB chunks: 8 x (1 + 3); chunks of 2 KiB: 8 x (4 + 0))
+    // (64 KiB chunks: 4 x (1 + 7), sparse 2 x (2 + 5); 8 KiB chunks: 8 x (1 + 3); chunks of 2 KiB: 8 x (4 + 0))
     g.slots = 512;
     uint32_t best = 0, best_near = 0;
     for (uint32_t wn = 1; wn <= 4; wn *= 2)
@@ -326,7 +326,8 @@ FarGeometry far_geometry(uint32_t ht_size, uint32_t cls, size_t batch, size_t fa
           continue;
         const uint32_t lds = wn * table + (wn + nf) * 2u * g.slots;
         if (lds <= kLdsPerCu && kLdsPerCu / round_up(lds, kLdsGranule) >= per_cu) {
-          if (per_cu * wn > best_near) {
+          // (sparse: pairs of LDS-table waves, so that two and a half device-table waves go with each)
+          if (per_cu * wn > best_near || (cls == kClassSparse && per_cu * wn == best_near && wn == 2)) {
             best_near = per_cu * wn;
             best = per_cu;
             g.near = wn;
@@ -341,8 +342,14 @@ FarGeometry far_geometry(uint32_t ht_size, uint32_t cls, size_t batch, size_t fa
       g.slots = kFarScratchSlots;
       best = 8;
     }
-    if (cls == kClassSparse && g.near > 0 && g.far > 3 * g.near)
-      g.far = 3 * g.near;
+    // sparse data (text): the device-table waves beyond two and a half per LDS-table wave only queue
+    // on the fabric (64 KiB chunks, 65 536 of them, LDS-table + device-table waves per CU: 4 + 8: 55.2
+    // GB/s, 4 + 10: 60.7, 4 + 11: 60.4, 4 + 12: 58.2, 4 + 14: 54.8)
+    if (cls == kClassSparse && g.near > 0) {
+      const uint32_t most = g.near >= 2 ? 5 * g.near / 2 : 3;
+      if (g.far > most)
+        g.far = most;
+    }
     g.groups = best * cus;
   }
   // no more device-table waves than the batch needs and the temp buffer has tables for

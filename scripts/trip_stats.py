@@ -22,7 +22,8 @@ if both:
     os.environ["HIPCOMP_LZ4_GEOMETRY"] = both
 names = ["trips", "sequences taken in trips", "trips ended by a match >= 16 bytes", "trips that took nothing", "pick: no match lane left in the span",
          "pick: clash (slot shared / stale)", "windows of the general path", "sequences followed without a look", "lanes moved (sum)",
-         "pick: more literals than a token holds", "wide form: sequences taken", "wide form: ... with the length off the window"]
+         "pick: more literals than a token holds", "wide form: sequences taken", "wide form: ... with the length off the window",
+         "runs trip: tried", "runs trip: no lane with a candidate", "runs trip: took sequences", "runs trip: sequences taken"]
 for dist in a.dist.split(","):
     if dist == "text":
         data = torch.from_numpy(bench.gen_text(a.chunks * bench.CHUNK)).to(dev)

@@ -21,6 +21,10 @@ between producer and consumer (every instruction is one, `s_nop N` is N + 1):
   H7  SALU writes M0  ->  LDS add-tid / LDS-DMA / s_sendmsg / s_movrel                1
   H8  transcendental VALU (v_exp, v_log, v_rcp, v_rsq, v_sqrt, v_sin, v_cos) writes
       a VGPR  ->  non-transcendental VALU that reads it                               1
+  H9  VALU writes a VGPR  ->  v_readlane / v_readfirstlane / v_writelane that reads
+      it (LLVM: VALUWriteVGPRReadlaneRead; met on the GPU in round 3: a v_readlane
+      opening an asm block read the value its VGPR held BEFORE the v_or3_b32 in
+      front of it)                                                                   1
 
 A violation with producer or consumer inside ";;#ASMSTART .. ;;#ASMEND" fails the
 build.  Pairs that lie wholly in compiler-scheduled code are reported as a
@@ -151,6 +155,9 @@ def check(path):
                 need, why = 1, "H7 SALU-written M0"
             elif pr["kind"] == "trans_vgpr" and is_valu and not mn.startswith(TRANS) and (read & pr["regs"]):
                 need, why = 1, "H8 transcendental result read by VALU"
+            elif pr["kind"] == "valu_vgpr" and mn.startswith(("v_readlane", "v_readfirstlane", "v_writelane")) \
+                    and (read & pr["regs"]):
+                need, why = 1, "H9 VALU-written VGPR read by a lane access"
             if why and pr["age"] < need:
                 if pr["in_asm"] or in_asm:
                     failures.append(f"{path}: {func}: {why}: `{pr['text']}` then `{raw.strip()}` after "

@@ -381,6 +381,16 @@ extern "C" int hipcompBatchedLZ4DebugTripStats(uint32_t* host16, int reset)
     return 2;
   return 0;
 }
+extern "C" int hipcompBatchedLZ4DebugTripLog(uint32_t* host_words, uint32_t* count, int reset)
+{
+  if (hipMemcpyFromSymbol(count, HIP_SYMBOL(g_trip_log_n), 4) != hipSuccess
+      || hipMemcpyFromSymbol(host_words, HIP_SYMBOL(g_trip_log), 4u << 16) != hipSuccess)
+    return 1;
+  uint32_t zero = 0;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_trip_log_n), &zero, 4) != hipSuccess)
+    return 2;
+  return 0;
+}
 #endif
 
 size_t lz4_compress_temp_bytes_used(uint32_t ht_size, size_t batch)

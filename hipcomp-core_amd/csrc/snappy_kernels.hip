@@ -271,7 +271,8 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         // lane in bits 8-13 -- s_bitset1_b64 and v_readlane look at the low six bits of their index only.
         {
           uint32_t then, tx = (uint32_t)t;
-          asm volatile("v_readlane_b32 %[then], %[follows], %[t]\n\t"
+          asm volatile("s_nop 0\n\t" // (check_asm_hazards.py H9: `follows` may have been made by the instruction in front)
+                       "v_readlane_b32 %[then], %[follows], %[t]\n\t"
                        "s_cmp_lt_i32 %[then], 0\n\t"
                        "s_cbranch_scc0 2f\n"
                        "1:\n\t"

@@ -52,8 +52,8 @@ def main(path):
            or "lz4_compress_kernel_both" in k]
     if len(mix) != 3:
         errors.append(f"expected 3 mix kernels (element size 1, 2, 4), found {len(mix)}")
-    if len(far) < 6:
-        errors.append(f"expected at least 6 far kernels, found {len(far)}")
+    if len(far) < 9:
+        errors.append(f"expected at least 9 far kernels (3 element sizes x lean, lean with chains, wide), found {len(far)}")
     for k in mix + far:
         s = sets.get(k, {})
         in_asm = False

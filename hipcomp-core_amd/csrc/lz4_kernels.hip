@@ -126,13 +126,16 @@ MixKernel mix_kernel_for(int elem_size)
   return elem_size == 1 ? lz4_compress_kernel_mix<1> : elem_size == 2 ? lz4_compress_kernel_mix<2>
                                                                       : lz4_compress_kernel_mix<4>;
 }
-FarKernel far_kernel_for(int elem_size, bool wide)
+template <int FORM>
+FarKernel far_kernel_of_form(int elem_size)
 {
-  if (wide)
-    return elem_size == 1 ? lz4_compress_kernel_far<1, true> : elem_size == 2 ? lz4_compress_kernel_far<2, true>
-                                                                               : lz4_compress_kernel_far<4, true>;
-  return elem_size == 1 ? lz4_compress_kernel_far<1, false> : elem_size == 2 ? lz4_compress_kernel_far<2, false>
-                                                                              : lz4_compress_kernel_far<4, false>;
+  return elem_size == 1 ? lz4_compress_kernel_far<1, FORM> : elem_size == 2 ? lz4_compress_kernel_far<2, FORM>
+                                                                             : lz4_compress_kernel_far<4, FORM>;
+}
+FarKernel far_kernel_for(int elem_size, uint32_t cls)
+{
+  return cls == kClassWide ? far_kernel_of_form<kFormWide>(elem_size)
+         : cls == kClassDense ? far_kernel_of_form<kFormChains>(elem_size) : far_kernel_of_form<kFormLean>(elem_size);
 }
 
 // more than 64 KiB of dynamic LDS has to be asked for, once per kernel and device
@@ -150,8 +153,8 @@ hipError_t raise_dynamic_lds_limit()
   for (int es = 1; es <= 4 && r == hipSuccess; es *= 2) {
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(mix_kernel_for(es)),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    for (int wide = 0; wide < 2 && r == hipSuccess; ++wide)
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(far_kernel_for(es, wide != 0)),
+    for (uint32_t cls = kClassDense; cls <= kClassWide && r == hipSuccess; ++cls)
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(far_kernel_for(es, cls)),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   g_lds_raised[dev].store(r == hipSuccess ? 1 : -(int)r, std::memory_order_release);
@@ -456,7 +459,7 @@ hipError_t lz4_launch_compress(
     const FarGeometry g = far_geometry(ht_size, cls, batch, far_tables ? far_capacity : 0);
     if (g.groups == 0 || g.lds_bytes > kLdsPerCu)
       return false;
-    far_kernel_for(elem_size, cls == kClassWide)<<<dim3(g.groups), dim3(g.waves() * kWave), g.lds_bytes, stream>>>(
+    far_kernel_for(elem_size, cls)<<<dim3(g.groups), dim3(g.waves() * kWave), g.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, g.near, g.slots,
         far_span(cls), (uint32_t)batch, header + cls,
         chunks_per_ticket((size_t)g.groups * g.waves()), cls, counts, all_lists);

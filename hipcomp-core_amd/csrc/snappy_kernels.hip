@@ -258,8 +258,6 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
       uint32_t follows = after | (next_hit << 8) | (easy ? 1u << 31 : 0u);
       uint32_t about = pick();
       while ((about >> 30) == 1u) {
-        asm("s_bitset1_b64 %0, %1" : "+s"(hit_lanes) : "s"(t));
-        asm("s_bitset1_b64 %0, %1" : "+s"(start_lanes) : "s"(start));
         if (touched != 0) {
           // lanes with the hash of one just taken are no longer easy to pass
           stale |= touched;
@@ -271,7 +269,10 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
         // lane in bits 8-13 -- s_bitset1_b64 and v_readlane look at the low six bits of their index only.
         {
           uint32_t then, tx = (uint32_t)t;
-          asm volatile("s_nop 0\n\t" // (check_asm_hazards.py H9: `follows` may have been made by the instruction in front)
+          // (the element pick() found is noted here, in front of the first v_readlane: `follows` may have
+          // been made by the instruction in front of this statement -- check_asm_hazards.py H9)
+          asm volatile("s_bitset1_b64 %[hits], %[t]\n\t"
+                       "s_bitset1_b64 %[starts], %[start]\n\t"
                        "v_readlane_b32 %[then], %[follows], %[t]\n\t"
                        "s_cmp_lt_i32 %[then], 0\n\t"
                        "s_cbranch_scc0 2f\n"
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
                        "s_cbranch_scc1 1b\n"
                        "2:"
                        : [then] "=&s"(then), [t] "+s"(tx), [starts] "+s"(start_lanes), [hits] "+s"(hit_lanes)
-                       : [follows] "v"(follows)
+                       : [follows] "v"(follows), [start] "s"(start)
                        : "scc");
           t = (int)(tx & 63u);
           start = then & 127u; // (= t + 4 + copy length - 4)

@@ -97,6 +97,9 @@ def test_hazard_guard_catches_what_it_is_there_for(tmp_path):
         "H1": ("\t;;#ASMSTART\n\tv_readfirstlane_b32 s4, v1\n\tv_readlane_b32 s5, v2, s4\n\t;;#ASMEND\n"),
         "H3": ("\t;;#ASMSTART\n\tv_add_u32_e32 v3, v1, v2\n\tv_mov_b32_dpp v4, v3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t;;#ASMEND\n"),
         "H5": ("\t;;#ASMSTART\n\tv_cmpx_eq_u32_e32 v1, v2\n\tv_readfirstlane_b32 s4, v1\n\t;;#ASMEND\n"),
+        # met on the GPU in round 3 (the chain walk of the LZ4 encoder wrote a sequence twice): the v_readlane that
+        # opens an asm statement right behind the compiler's instruction that made its source register
+        "H9": ("\tv_or3_b32 v17, v42, v17, v15\n\t;;#ASMSTART\n\tv_readlane_b32 s27, v17, 0\n\ts_cmp_lt_i32 s27, 0\n\t;;#ASMEND\n"),
     }
     for code, body in cases.items():
         r = _haz(_snippet(tmp_path, body))
@@ -104,6 +107,7 @@ def test_hazard_guard_catches_what_it_is_there_for(tmp_path):
     fine = {
         "H2 with the s_nop": cases["H2"].replace("\tglobal_atomic_add", "\ts_nop 0\n\tglobal_atomic_add"),
         "H1 four states on": ("\t;;#ASMSTART\n\tv_readfirstlane_b32 s4, v1\n\ts_nop 3\n\tv_readlane_b32 s5, v2, s4\n\t;;#ASMEND\n"),
+        "H9 one state on": cases["H9"].replace("\tv_readlane_b32 s27", "\ts_mov_b64 s[38:39], 1\n\tv_readlane_b32 s27"),
         "SALU-made lane select": ("\t;;#ASMSTART\n\ts_add_u32 s4, s6, 1\n\tv_readlane_b32 s5, v2, s4\n\t;;#ASMEND\n"),
     }
     for what, body in fine.items():

@@ -6,7 +6,7 @@
 # headline: rocprofv3 --kernel-trace --stats of the default bench command.
 # rows:     per bench row (bench.py extra_keys[].row) kernel trace + stats, and the HBM-side traffic from
 #           separate --pmc FETCH_SIZE / WRITE_SIZE passes -> profiles-ready $O/${R}_rows.json
-# pmc:      instruction / cycle counts per window (uniform, LDS shape), per sequence (harness: far kernel;
+# pmc:      instruction / cycle counts per window (uniform, LDS shape), per sequence (harness, text, runs: far kernels;
 #           both decoders on harness and text) and per KiB (Snappy).
 # Output under gpurun_out/prof_$R/; copy what is to be kept into profiles/.
 set -e
@@ -44,7 +44,7 @@ if [ $PART = pmc ] || [ $PART = all ]; then
   SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
   SQ2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
   # (harness / text: 20000 chunks, so that the far kernel has all its waves)
-  for DN in uniform:5000 harness:20000 text:20000; do
+  for DN in uniform:5000 harness:20000 text:20000 runs:20000; do
     D=${DN%:*}; N=${DN#*:}
     rm -rf $O/sq1_$D $O/sq2_$D
     rocprofv3 --kernel-trace --output-format csv --pmc $SQ1 -d $O/sq1_$D -- python3 scripts/quick_lz4.py --chunks $N --dist $D --reps 1 --count-sequences > $O/sq1_$D.log 2>&1
@@ -52,7 +52,7 @@ if [ $PART = pmc ] || [ $PART = all ]; then
   done
   { echo "# lz4 compress kernel (mix shape), 5000 x 64 KiB uniform chunks, per 61-byte window per wave (= per-dispatch counter / 5 375 000 windows); SQ_*CYCLES, SQ_WAIT*, SQ_ACTIVE* are quad-cycles";
     python3 scripts/pmc_per_window.py 5375000 $O/sq1_uniform $O/sq2_uniform; } > $O/${R}_lz4_pmc_per_window_uniform_char.txt
-  for D in harness text; do
+  for D in harness text runs; do
     SEQ=$(grep -o "sequences_per_chunk=[0-9.]*" $O/sq1_$D.log | cut -d= -f2)
     U=$(python3 -c "print(20000*$SEQ)")
     { echo "# lz4 compress kernel (far kernel), 20000 x 64 KiB $D chunks as bytes, per LZ4 sequence per wave ($SEQ sequences per chunk); quad-cycles as above";

@@ -559,3 +559,34 @@ def test_lean_form_near_the_end_of_a_chunk(hc, oracle, reflib, cuda, lz4_shape, 
         assert got[i] == want[i % len(base)], f"chunk {i} ({len(chunks[i])} bytes) {tname} shape={lz4_shape}: kernel != oracle"
     _round_trip(hc, mine, chunks, dtype)
     compare_with_reference(reflib, "chunks around the lean form's margin", _reference_agrees(hc, base, dtype, 65536, want, tname))
+
+
+@pytest.mark.parametrize("tname,dtype,es", TYPES)
+def test_chains_of_sequences_without_literals(hc, oracle, reflib, cuda, lz4_shape, tname, dtype, es):
+    """Data of few distinct values is one short match after the other, none with a literal; the dense
+    class's kernel writes such a chain from a window's first lane on the short way (lz4_far.hiph,
+    kFormChains), a match of 16 bytes or more behind it ends the trip.  Alphabets of 2 ... 16 values of
+    1, 2, 4 and 8 bytes (few values: long matches right behind short ones, chains of one lane; many:
+    chains broken by literals), chunk lengths that put the chain's end at every distance from the
+    lean form's margin -- each chunk against the oracle and the reference build, then the round trip.
+    (Round 3: a chain walk whose first v_readlane read a stale register wrote the chain's last
+    sequence twice -- 25 times in the 64 KiB chunk of the edge set; check_asm_hazards.py H9.)"""
+    chunks = []
+    k = 0
+    for values in (2, 3, 4, 5, 8, 16):
+        for width in (1, 2, 4, 8):
+            for n in (65536, 65536 - 36, 20000 + 4 * k, 3000 + k):
+                rng = np.random.default_rng(9000 + k)
+                alphabet = rng.integers(0, 256, (values, width), dtype=np.uint8)
+                c = alphabet[rng.integers(0, values, n // width + 1)].reshape(-1)[:n].tobytes()
+                chunks.append(c[: len(c) // es * es])
+                k += 1
+    base = chunks
+    chunks = base * 16        # (1536 chunks: device-table waves beside the LDS-table ones)
+    want = [_want(oracle, c, es, 65536) for c in base]
+    src, mine = _compress(hc, chunks, dtype, 65536)
+    got = mine.to_host_chunks()
+    for i in range(len(chunks)):
+        assert got[i] == want[i % len(base)], f"chunk {i} ({len(chunks[i])} bytes) {tname} shape={lz4_shape}: kernel != oracle"
+    _round_trip(hc, mine, chunks, dtype)
+    compare_with_reference(reflib, "chains of sequences without literals", _reference_agrees(hc, base, dtype, 65536, want, tname))

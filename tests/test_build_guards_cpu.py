@@ -99,6 +99,9 @@ def test_hazard_guard_catches_what_it_is_there_for(tmp_path):
         "H5": ("\t;;#ASMSTART\n\tv_cmpx_eq_u32_e32 v1, v2\n\tv_readfirstlane_b32 s4, v1\n\t;;#ASMEND\n"),
         # met on the GPU in round 3 (the chain walk of the LZ4 encoder wrote a sequence twice): the v_readlane that
         # opens an asm statement right behind the compiler's instruction that made its source register
+        # a VALU-written SGPR as a VALU source two instructions too early (the mix kernel's v_readlane of window
+        # lane 31's slot in front of the compare of its insert rule, until round 3)
+        "H10 ": ("\tv_readlane_b32 s10, v91, 63\n\t;;#ASMSTART\n\tv_cmp_ne_u32_e32 vcc, s10, v91\n\t;;#ASMEND\n"),
         "H9": ("\tv_or3_b32 v17, v42, v17, v15\n\t;;#ASMSTART\n\tv_readlane_b32 s27, v17, 0\n\ts_cmp_lt_i32 s27, 0\n\t;;#ASMEND\n"),
     }
     for code, body in cases.items():
@@ -113,6 +116,9 @@ def test_hazard_guard_catches_what_it_is_there_for(tmp_path):
     for what, body in fine.items():
         r = _haz(_snippet(tmp_path, body))
         assert r.returncode == 0, (what, r.stderr)
+    # v_cmp -> v_cndmask on VCC back to back inside asm: reported with its count, not refused (see the script's header)
+    r = _haz(_snippet(tmp_path, "\t;;#ASMSTART\n\tv_cmp_ne_u32_e32 vcc, 0xffff, v2\n\tv_cndmask_b32_e32 v0, v1, v2, vcc\n\t;;#ASMEND\n"))
+    assert r.returncode == 0 and "H10v" in r.stderr and ": 1" in r.stderr, r.stderr
     # the same pair wholly in compiler-scheduled code is not ours: reported as calibration, not as a failure
     r = _haz(_snippet(tmp_path, cases["H1"].replace("\t;;#ASMSTART\n", "").replace("\t;;#ASMEND\n", "")))
     assert r.returncode == 0 and "calibration" in r.stderr

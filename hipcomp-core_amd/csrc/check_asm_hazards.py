@@ -21,15 +21,12 @@ between producer and consumer (every instruction is one, `s_nop N` is N + 1):
   H7  SALU writes M0  ->  LDS add-tid / LDS-DMA / s_sendmsg / s_movrel                1
   H8  transcendental VALU (v_exp, v_log, v_rcp, v_rsq, v_sqrt, v_sin, v_cos) writes
       a VGPR  ->  non-transcendental VALU that reads it                               1
-  H10 VALU writes an SGPR  ->  VALU that reads it as a source operand (LLVM:
-      VALUWriteSGPRVALURead)                                                          2
-  H10v ... writes VCC  ->  VALU that reads VCC (v_cndmask's mask, a carry-in): the same
-      LLVM rule, and the compiler puts `s_nop 1` between the two in its own code.  Inside asm
-      blocks this pair is REPORTED, NOT REFUSED: the walk of the LZ4 mix kernel has several
-      hundred `v_cmp` / `v_cndmask` pairs back to back (lz4_mix.hiph), every window of every
-      parity run goes through them (~1e11 executions bit-exact against the reference's
-      kernels), and two wait states each would cost the headline kernel several per cent.
-      New code should not add to the count.
+  H10 VALU writes an SGPR or VCC  ->  VALU that reads it as an operand -- an SGPR source,
+      v_cndmask's mask, a carry-in (LLVM: VALUWriteSGPRVALURead; the compiler puts `s_nop 1`
+      between a v_cmp and the v_cndmask on its VCC).  Until round 3 the walk of the LZ4 mix
+      kernel had several hundred v_cmp / v_cndmask pairs back to back on VCC (never wrong in
+      any parity run); they are compares into SGPR pairs now, four windows at a time, with
+      the selects behind them (lz4_mix.hiph) -- which also runs 1.6 % faster               2
   H9  VALU writes a VGPR  ->  v_readlane / v_readfirstlane / v_writelane that reads
       it (LLVM: VALUWriteVGPRReadlaneRead; met on the GPU in round 3: a v_readlane
       opening an asm block read the value its VGPR held BEFORE the v_or3_b32 in
@@ -104,7 +101,6 @@ def is_dpp(mn, ops):
 def check(path):
     text = open(path).read()
     failures, calibration = [], 0
-    tolerated = {}
     func, in_asm = None, False
     # recent producers: list of dicts(kind, regs, age, in_asm, text)
     recent = []
@@ -173,14 +169,9 @@ def check(path):
                     and (read & pr["regs"]):
                 need, why = 1, "H9 VALU-written VGPR read by a lane access"
             elif pr["kind"] == "valu_sgpr" and is_valu and (read & pr["regs"]) and not (lane_select & pr["regs"]):
-                if (read & pr["regs"]) <= {"vcc_lo", "vcc_hi"}:
-                    need, why = 2, "H10v VALU-written VCC read by VALU"
-                else:
-                    need, why = 2, "H10 VALU-written SGPR read by VALU"
+                need, why = 2, "H10 VALU-written SGPR / VCC read by VALU"
             if why and pr["age"] < need:
-                if why.startswith("H10v") and (pr["in_asm"] or in_asm):
-                    tolerated[func] = tolerated.get(func, 0) + 1
-                elif pr["in_asm"] or in_asm:
+                if pr["in_asm"] or in_asm:
                     failures.append(f"{path}: {func}: {why}: `{pr['text']}` then `{raw.strip()}` after "
                                     f"{pr['age']} wait state(s), {need} needed")
                 else:
@@ -205,17 +196,13 @@ def check(path):
                                    in_asm=in_asm, text=raw.strip()))
         elif mn.startswith("s_") and ops and "m0" in operand_regs(ops[0]) and not mn.startswith(("s_cmp", "s_waitcnt")):
             recent.append(dict(kind="salu_m0", regs={"m0"}, age=0, in_asm=in_asm, text=raw.strip()))
-    return failures, calibration, tolerated
+    return failures, calibration
 
 
 def main(paths):
     bad = 0
     for p in paths:
-        failures, calibration, tolerated = check(p)
-        if tolerated:
-            sys.stderr.write(f"check_asm_hazards: {p}: H10v (v_cmp -> v_cndmask on VCC back to back inside asm) tolerated in "
-                             + ", ".join(f"{re.sub(r'^_ZN5hcamd12_GLOBAL__N_1[0-9]*', '', k)[:40]}: {v}" for k, v in sorted(tolerated.items()))
-                             + "\n")
+        failures, calibration = check(p)
         for f in failures:
             sys.stderr.write("check_asm_hazards: " + f + "\n")
         if calibration:

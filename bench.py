@@ -314,7 +314,7 @@ def cpu_codec_baseline(codec: str, sample, reps: int = 2):
                       f"ratio {total / max(ct.value, 1):.3f}"}
 
 
-def measure_row(hc, lib, codec: str, opts, data, label: dict, key: str, reps: int = 3):
+def measure_row(hc, lib, codec: str, opts, data, label: dict, key: str, reps: int = 5):
     """One extra row: compress / decompress of `data` through `codec`.  `key` names the row in
     profiles/r03_rows.json (the rocprof passes of the same workload)."""
     import torch

@@ -18,6 +18,7 @@ from . import api  # noqa: F401  (loads libhipcomp.so, raises if missing)
 from .api import (  # noqa: F401
     HipcompLibrary,
     default_library,
+    knobs_library,
     hipcompStatus,
     hipcompType,
     LZ4Opts,
@@ -31,6 +32,7 @@ __all__ = [
     "batch",
     "HipcompLibrary",
     "default_library",
+    "knobs_library",
     "hipcompStatus",
     "hipcompType",
     "LZ4Opts",

@@ -27,6 +27,9 @@ import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "lib", "libhipcomp.so")
+# the same sources built with -DHC_MEASUREMENT_KNOBS (csrc/Makefile VARIANT=knobs): honours
+# HIPCOMP_LZ4_SHAPE / HIPCOMP_LZ4_GEOMETRY / HIPCOMP_LZ4_SPAN -- tests and measurement scripts only
+KNOBS_LIB = os.path.join(_HERE, "lib", "libhipcomp_knobs.so")
 
 
 class hipcompStatus:
@@ -145,6 +148,17 @@ class HipcompLibrary:
 
 
 _default = None
+
+
+_knobs = None
+
+
+def knobs_library() -> HipcompLibrary:
+    """The test / measurement build that reads the launch-shape knobs from the environment."""
+    global _knobs
+    if _knobs is None:
+        _knobs = HipcompLibrary(KNOBS_LIB, codecs=_available_codecs(KNOBS_LIB))
+    return _knobs
 
 
 def default_library() -> HipcompLibrary:

@@ -12,8 +12,6 @@
 #include "cascaded_launch.hpp"
 #include "host_common.hpp"
 
-#include <cstdlib>
-#include <cstring>
 
 using namespace hcamd;
 
@@ -43,14 +41,6 @@ bool elem_size_of(hipcompType_t t, int& s)
   }
 }
 
-} // namespace
-
-namespace {
-bool chunk_size_extension()
-{
-  const char* e = std::getenv("HIPCOMP_CASCADED_CHUNK_SIZE");
-  return e && std::strcmp(e, "honour") == 0;
-}
 } // namespace
 
 extern "C" {
@@ -103,15 +93,8 @@ hipcompStatus_t hipcompBatchedCascadedCompressAsync(
       reinterpret_cast<uint8_t* const*>(device_compressed_ptrs),
       device_compressed_bytes, batch_size, (int)format_opts.type, s, R, D,
       format_opts.use_bp ? 1 : 0,
-      // chunk_size: the reference ignores the field (cascaded.h:93-100) and cuts
-      // partitions into 4096-byte sub-chunks, and so does this by default -- a
-      // caller of the reference that passes 8192 keeps getting streams the
-      // reference reads.  With HIPCOMP_CASCADED_CHUNK_SIZE=honour in the
-      // environment 8192 and 16384 are honoured (an extension: such streams need
-      // this library's decoder); every other value means 4096.
-      chunk_size_extension() && (format_opts.chunk_size == 8192 || format_opts.chunk_size == 16384)
-          ? (uint32_t)format_opts.chunk_size
-          : 4096u,
+      // (format_opts.chunk_size: the reference ignores the field -- cascaded.h:93-100 -- and cuts partitions
+      // into 4096-byte sub-chunks whatever it says, and so does this)
       stream);
   std::string why;
   if (!launch_ok("cascaded compression kernel", why))

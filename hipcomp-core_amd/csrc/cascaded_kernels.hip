@@ -6,21 +6,26 @@
 //
 //   reference                                 here
 //   ----------------------------------------  -------------------------------
-//   one 128-thread block per partition,       one WAVE per partition, four
-//   6+ __syncthreads per layer, hipCUB        partitions per 256-thread block:
-//   BlockScan / BlockReduce                   no block barrier at all; run
-//                                             ends ranked with one ballot +
-//                                             popcount per 64 elements, min /
-//                                             max by DPP-style shuffles
-//   RLE: count pass, scan, scatter pass,      one pass: value, rank and run
-//   adjacent-difference pass                  length from the same ballot
-//   bit-packed arrays built in LDS, then      packed words go straight from
-//   copied out word by word                   the LDS element array to HBM
-//   decompress: 4 launches, type taken from   4 launches (LDS sized per
-//   partition 0, RLE expand = 1 thread/run    width), type taken from EACH
-//   (a 4096-long run = 4096 serial stores)    partition; RLE expand = run
-//                                             markers + DPP running max;
-//                                             delta = DPP prefix sum
+//   one 128-thread block per partition,       one WAVE per partition and workgroup:
+//   6+ __syncthreads per layer, hipCUB        no barrier at all
+//   BlockScan / BlockReduce
+//   RLE: count pass, scan, scatter pass,      ONE pass in a register-blocked layout
+//   adjacent-difference pass, a thread        (round 4): a lane holds 16 CONSECUTIVE
+//   per element                               elements of the sub-chunk, finds its run
+//                                             ends with 16 compares, one wave scan ranks
+//                                             them, every run end stores its value and
+//                                             its length itself -- 1/5 of the
+//                                             instructions of the element-per-lane form
+//                                             of rounds 1-3 (one ballot, one rank and
+//                                             one store group per 64 elements)
+//   bit-packed arrays built in LDS, then      packed words go straight from the LDS
+//   copied out word by word                   element array to HBM
+//   decompress: 4 launches, type taken from   4 launches (LDS sized per width), type
+//   partition 0, RLE expand = 1 thread/run    taken from EACH partition; RLE expand =
+//   (a 4096-long run = 4096 serial stores)    run markers + a running maximum and delta
+//                                             = a prefix sum, both in the blocked layout:
+//                                             16 steps inside the lane, one wave scan
+//                                             across the lanes
 //
 // Bytes the reference leaves undefined (stale LDS / unwritten gaps,
 // SURVEY.md App. C.4) are written as 0 here, so the output is deterministic.
@@ -35,14 +40,14 @@ namespace hcamd {
 
 namespace {
 
-// Sub-chunk size CB (a template parameter of the kernels): 4096 is the reference's
-// (CascadedKernels.hiph:88, hard-wired; its opts.chunk_size is "not currently used",
-// cascaded.h:93-100); 8192 and 16384 are honoured here (the 160 KiB
-// of LDS permit them).  Streams with the larger sub-chunks say so in the high nibble
-// of header byte 2 (use_bp, 0 or 1 in the reference): 0 = 4096, 1 = 8192, 2 = 16384.
+// Sub-chunks are the reference's 4096 bytes (CascadedKernels.hiph:88, hard-wired there; its
+// opts.chunk_size is "not currently used", cascaded.h:93-100, and is ignored here as well).
+// (Rounds 2-3 honoured 8192 / 16384 as an opt-in extension of the format: ratio +1 %, -26 ... -56 %
+// throughput, eight more decompress launches -- measured useless and removed in round 4.)
 constexpr uint32_t kPartMeta = 8;
+constexpr uint32_t CB = 4096;
 #ifndef HC_CASC_WAVES
-#define HC_CASC_WAVES 1 // 10 KiB of LDS per wave: separate blocks pack 14 per CU, 4-wave blocks only 12
+#define HC_CASC_WAVES 1 // 6 KiB of LDS per wave: separate blocks pack 25 per CU
 #endif
 constexpr int kWavesPerBlock = HC_CASC_WAVES;
 
@@ -54,34 +59,113 @@ template <> struct UIntOf<8> { typedef uint64_t type; typedef int64_t stype; };
 
 __device__ __forceinline__ uint32_t ru(uint32_t a, uint32_t b) { return (a + b - 1) / b * b; }
 
-template <int CB>
-__host__ __device__ constexpr uint32_t elem_buf_bytes() { return CB + 16; }
+// ---------------------------------------------------------------------------
+// The register-blocked layout.  A ROUND is 64 x E consecutive elements of an LDS array, lane t
+// holding elements [t E, (t + 1) E) of it in registers: E = 16 (8 for 8-byte elements), i.e. a
+// round is 1024 elements (512) and a 4096-byte sub-chunk is 4 / 2 / 1 / 1 rounds of 1- / 2- /
+// 4- / 8-byte elements.  What an element-per-lane layout does with a ballot or a wave scan per
+// 64 elements is E steps inside the lane here plus ONE wave scan per round.
+// ---------------------------------------------------------------------------
+template <int S>
+struct Blocked
+{
+  static constexpr int E = S == 8 ? 8 : 16;    // elements per lane and round
+  static constexpr int W = E * S / 4;          // 32-bit words per lane and round: 4, 8, 16, 16
+  static constexpr uint32_t ROUND = kWave * E; // elements per round
+};
 
-template <int S, int CB>
+// encoder: behind the element buffer lie the E + 1 sentinels of wave_rle
+__host__ __device__ constexpr uint32_t enc_buf_bytes() { return CB + 80; }
+// decoder: one element more (the head of a delta layer)
+__host__ __device__ constexpr uint32_t dec_buf_bytes() { return CB + 16; }
+
+template <int S>
 __host__ __device__ constexpr uint32_t wave_lds_bytes()
 {
-  // encoder: one element buffer (every layer works in place) + run-count
-  // array + 64-byte metadata image
-  return elem_buf_bytes<CB>() + (CB / S) * 2 + 64;
+  // encoder: one element buffer (every layer works in place) + run-length
+  // array + 64-byte metadata image; 4-byte elements (the fast path, see rle16): the two padded arrays
+  return S == 4 ? (1024 + 32) * 4 + (1024 * 2 + 32 * 4) : enc_buf_bytes() + (CB / S) * 2 + 64;
 }
 
 // decoder: the head of the compressed sub-chunk (metadata + arrays) is staged
-// in LDS, stage_words<CB>() 32-bit words, stage_per_lane<CB>() per lane, loaded one
+// in LDS, kStageWords 32-bit words, kStagePerLane per lane, loaded one
 // sub-chunk ahead into registers.  Arrays that do not fit are read from HBM
 // directly.  1 KiB holds the whole sub-chunk of a column that compresses 4x or
-// better and lets a CU hold 14 waves of the 4-byte / 4096 launch (2 KiB: 12;
+// better and lets a CU hold 14 waves of the 4-byte launch (2 KiB: 12;
 // measured 960 vs 843 GB/s at ratio 5.3, 770 vs 840 GB/s at ratio 2.2).
-// (per 4096 bytes of sub-chunk; the larger sub-chunks stage 2 and 4 KiB, which costs
-// their launches no resident wave)
-template <int CB>
-__host__ __device__ constexpr uint32_t stage_per_lane() { return 4u * (CB / 4096); }
-template <int CB>
-__host__ __device__ constexpr uint32_t stage_words() { return stage_per_lane<CB>() * kWave; }
-template <int S, int CB>
+constexpr uint32_t kStagePerLane = 4;
+constexpr uint32_t kStageWords = kStagePerLane * kWave;
+template <int S>
 __host__ __device__ constexpr uint32_t dec_lds_bytes()
 {
   // two element buffers + run markers + staged sub-chunk
-  return 2 * elem_buf_bytes<CB>() + (CB / S) * 2 + stage_words<CB>() * 4;
+  return 2 * dec_buf_bytes() + (CB / S) * 2 + kStageWords * 4;
+}
+
+// E elements p[0 .. E) of an LDS array (p 16-byte aligned) into registers
+template <typename UT>
+__device__ __forceinline__ void load_block(const UT* p, UT (&v)[Blocked<sizeof(UT)>::E])
+{
+  constexpr int S = sizeof(UT), E = Blocked<S>::E, W = Blocked<S>::W;
+  uint32_t w[W];
+  const u32x4* q = reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) {
+    const u32x4 t = q[i];
+    w[4 * i] = t.x;
+    w[4 * i + 1] = t.y;
+    w[4 * i + 2] = t.z;
+    w[4 * i + 3] = t.w;
+  }
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    if (S == 8)
+      v[k] = (UT)((uint64_t)w[(2 * k) % W] | ((uint64_t)w[(2 * k + 1) % W] << 32));
+    else if (S == 4)
+      v[k] = (UT)w[k % W];
+    else if (S == 2)
+      v[k] = (UT)(w[(k / 2) % W] >> (16 * (k & 1)));
+    else
+      v[k] = (UT)(w[(k / 4) % W] >> (8 * (k & 3)));
+  }
+}
+
+// ... and back
+template <typename UT>
+__device__ __forceinline__ void store_block(UT* p, const UT (&v)[Blocked<sizeof(UT)>::E])
+{
+  constexpr int S = sizeof(UT), E = Blocked<S>::E, W = Blocked<S>::W;
+  uint32_t w[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    if (S == 8)
+      w[i] = (uint32_t)((uint64_t)v[(i / 2) % E] >> (32 * (i & 1)));
+    else if (S == 4)
+      w[i] = (uint32_t)v[i % E];
+    else if (S == 2)
+      w[i] = (uint32_t)v[(2 * i) % E] | ((uint32_t)v[(2 * i + 1) % E] << 16);
+    else
+      w[i] = (uint32_t)v[(4 * i) % E] | ((uint32_t)v[(4 * i + 1) % E] << 8) | ((uint32_t)v[(4 * i + 2) % E] << 16)
+             | ((uint32_t)v[(4 * i + 3) % E] << 24);
+  }
+  u32x4* q = reinterpret_cast<u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) {
+    u32x4 t = {w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+    q[i] = t;
+  }
+}
+
+// the value of the lane below (lane 0: `first`), by the DPP crossbar
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t first, int lane)
+{
+  const uint32_t u = dpp_u32<0x138, 0xF>(v); // wave_shr:1
+  return lane == 0 ? first : u;
+}
+__device__ __forceinline__ uint64_t from_lane_below(uint64_t v, uint64_t first, int lane)
+{
+  const uint64_t u = (uint64_t)dpp_u32<0x138, 0xF>((uint32_t)v) | ((uint64_t)dpp_u32<0x138, 0xF>((uint32_t)(v >> 32)) << 32);
+  return lane == 0 ? first : u;
 }
 
 // ---- wave reductions (64 lanes) -------------------------------------------
@@ -105,34 +189,91 @@ __device__ __forceinline__ T wave_max(T v)
 }
 
 // ---- RLE of n elements: values, run lengths, number of runs ----------------
-// (reference block_rle_compress :124-241)
+// (reference block_rle_compress :124-241).  In place: the values of the runs are
+// compacted to x[0 .. m), their lengths go to cnts[0 .. m).  Register-blocked: a
+// lane compares its E elements with their right neighbours (the last one with the
+// first element of the lane above: one more LDS read), a wave scan of the lanes'
+// counts ranks the run ends, a running maximum of "where the last run ended below
+// me" gives the first one its length, and every run end then stores value and
+// length at its rank -- a round's loads all come before its stores (LDS operations
+// of a wave execute in order) and a round writes at or below what it has read.
+// E + 1 sentinels unlike x[n - 1] behind the last element make the last run end
+// like any other and keep the lanes beyond n quiet without a compare per element.
 template <typename UT>
-__device__ __forceinline__ uint32_t wave_rle(
-    const UT* in, uint32_t n, UT* vals, uint16_t* cnts, int lane)
+__device__ __forceinline__ uint32_t wave_rle(UT* x, uint32_t n, uint16_t* cnts, int lane)
 {
+  constexpr int S = sizeof(UT), E = Blocked<S>::E;
+  if (n == 0)
+    return 0;
+  {
+    const UT last = x[n - 1];
+    lds_lane_exchange_fence();
+    if (lane <= E)
+      x[n + (uint32_t)lane] = (UT)~last;
+    lds_lane_exchange_fence();
+  }
   uint32_t m = 0, prev_end = 0;
-  const uint64_t below_me = (1ull << lane) - 1;
-  for (uint32_t base = 0; base < n; base += kWave) {
-    const uint32_t i = base + (uint32_t)lane;
-    const bool active = i < n;
-    // (read whether or not the lane has an element: the buffer holds a multiple
-    // of 64 elements and one more, and what lies behind n is not used)
-    const UT v = in[i];
-    const UT nx = in[i + 1];
-    const bool is_end = active && (i + 1 == n || nx != v);
-    const uint64_t mask = wave_ballot(is_end);
-    const uint64_t below = mask & below_me;
-    const uint32_t rank = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    const uint32_t pe = below ? base + 64u - (uint32_t)__builtin_clzll(below) : prev_end;
-    if (is_end) {
-      vals[rank] = v;
-      cnts[rank] = (uint16_t)(i + 1 - pe);
+  for (uint32_t base = 0; base < n; base += Blocked<S>::ROUND) {
+    const uint32_t pos0 = base + (uint32_t)lane * E;
+    const bool active = pos0 < n;
+    UT v[E];
+    UT nx = 0;
+    uint32_t cnt = 0, last_end = 0;
+    bool f[E];
+    if (active) {
+      load_block(x + pos0, v);
+      nx = x[pos0 + E];
     }
-    m += (uint32_t)__builtin_popcountll(mask);
-    if (mask)
-      prev_end = base + 64u - (uint32_t)__builtin_clzll(mask);
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      f[k] = active && v[k] != (k + 1 < E ? v[(k + 1) % E] : nx);
+      cnt += f[k] ? 1u : 0u;
+      last_end = f[k] ? pos0 + (uint32_t)k + 1u : last_end;
+    }
+    const uint32_t incl = wave_scan_add_u32(cnt);
+    const uint32_t ends = wave_scan_max_u32(last_end); // (inclusive; positions grow with the lane)
+    uint32_t rank = m + incl - cnt;
+    // where the run that ends first in this lane began: behind the last end of the lanes below
+    uint32_t start = max(prev_end, dpp_u32<0x138, 0xF>(ends));
+    lds_lane_exchange_fence();
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      if (f[k]) {
+        const uint32_t end = pos0 + (uint32_t)k + 1u;
+        x[rank] = v[k];
+        cnts[rank] = (uint16_t)(end - start);
+        start = end;
+        ++rank;
+      }
+    }
+    lds_lane_exchange_fence();
+    m += read_lane(incl, 63);
+    prev_end = max(prev_end, read_lane(ends, 63));
   }
   return m;
+}
+
+// ---- delta of n >= 1 elements in place: x[i] = x[i + 1] - x[i], i < n - 1 ----
+// (reference block_delta_compress :317-328; wrap-around arithmetic).  Blocked as above;
+// what lands at and behind n - 1 is not used.
+template <typename UT>
+__device__ __forceinline__ void wave_delta(UT* x, uint32_t n, int lane)
+{
+  constexpr int S = sizeof(UT), E = Blocked<S>::E;
+  for (uint32_t base = 0; base + 1 < n; base += Blocked<S>::ROUND) {
+    const uint32_t pos0 = base + (uint32_t)lane * E;
+    if (pos0 + 1 < n) {
+      UT v[E], d[E];
+      load_block(x + pos0, v);
+      const UT nx = x[pos0 + E];
+      lds_lane_exchange_fence();
+#pragma unroll
+      for (int k = 0; k < E; ++k)
+        d[k] = (UT)((k + 1 < E ? v[(k + 1) % E] : nx) - v[k]);
+      store_block(x + pos0, d);
+    }
+    lds_lane_exchange_fence();
+  }
 }
 
 // ---- one array to HBM (reference block_write :646-680 / block_bitpack) ----
@@ -262,8 +403,349 @@ __device__ __forceinline__ uint32_t chunk_metadata_size(int R, int D)
   return ru((uint32_t)(4 + 4 * (R + 1)), (uint32_t)S) + ru((uint32_t)(S * D), 4u);
 }
 
-template <int S, int CB>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kernel(
+// ---------------------------------------------------------------------------
+// 4-byte elements: the encoder's fast path (round 4).  PMC on the round-3 kernel and on the
+// blocked RLE above said the same thing: the LDS is what the 25 waves of a CU queue on (70 - 83 %
+// busy, half of it bank conflicts of the packer's gathers, then of the blocked scatter), so this
+// path is built around LDS cycles:
+//  * the array a layer works on stays in REGISTERS between layers where it can: 16 registers hold
+//    a sub-chunk element-per-lane (v[k] = element 64 k + lane), loaded from HBM (first layer) or LDS;
+//    a delta layer is register arithmetic (the right neighbour by one DPP move) and hands its
+//    registers to the RLE that follows;
+//  * RLE: per 64 elements one compare, one ballot, one rank (mbcnt) and one store group -- the run
+//    ends of a step go to CONSECUTIVE ranks, so neither the value store nor the end-position store
+//    has a bank conflict.  What is stored per run is where it ENDS; lengths are differences of those
+//    and are taken by the packer in registers;
+//  * the compacted arrays lie in LDS with one dword of padding behind every 32 elements, so that
+//    the packer can take 32 consecutive elements per lane (132-byte / 68-byte lane stride: odd in
+//    dwords, conflict-free) -- 32 elements are a whole number of output words whatever the bit
+//    width, so a lane packs its elements without a neighbour, by compile-time shifts (one
+//    v_lshl_or_b32 per element for the bit widths met in practice), and minimum and maximum come
+//    out of the same registers: no pass of its own, no gather;
+//  * the chunk metadata image is a register (lane j = word j), not LDS: 4224 + 2176 bytes per wave,
+//    25 waves per CU as before.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kX4Bytes = (1024 + 32) * 4;     // 1024 elements, padded
+constexpr uint32_t kE4Bytes = 1024 * 2 + 32 * 4;   // 1024 run ends (u16), padded
+__device__ __forceinline__ uint32_t x4_addr(uint32_t i) { return (i + (i >> 5)) << 2; }         // byte offset of element i
+__device__ __forceinline__ uint32_t e4_addr(uint32_t i) { return (i << 1) + ((i >> 5) << 2); }  // ... of run end i
+
+__device__ __forceinline__ uint32_t lanes_below_me(uint64_t mask, uint32_t add)
+{
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, add));
+}
+
+// the value of the lane above (lane 63: `last`): one DPP move (wave_shl:1; the lane without a source keeps `last`)
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v, uint32_t last)
+{
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130, 0xF, 0xF, false);
+}
+
+// 64-lane reductions on the DPP crossbar: the result is lane 63's
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+{
+#define HC_STEP(CTRL, MASK)                                                                          \
+  {                                                                                                  \
+    const int32_t u = __builtin_amdgcn_update_dpp(v, v, CTRL, MASK, 0xF, false);                     \
+    v = u < v ? u : v;                                                                               \
+  }
+  HC_STEP(0x111, 0xF) HC_STEP(0x112, 0xF) HC_STEP(0x114, 0xF) HC_STEP(0x118, 0xF) HC_STEP(0x142, 0xA) HC_STEP(0x143, 0xC)
+#undef HC_STEP
+  return (int32_t)read_lane((uint32_t)v, 63);
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
+{
+#define HC_STEP(CTRL, MASK)                                                                          \
+  {                                                                                                  \
+    const int32_t u = __builtin_amdgcn_update_dpp(v, v, CTRL, MASK, 0xF, false);                     \
+    v = u > v ? u : v;                                                                               \
+  }
+  HC_STEP(0x111, 0xF) HC_STEP(0x112, 0xF) HC_STEP(0x114, 0xF) HC_STEP(0x118, 0xF) HC_STEP(0x142, 0xA) HC_STEP(0x143, 0xC)
+#undef HC_STEP
+  return (int32_t)read_lane((uint32_t)v, 63);
+}
+
+// the n elements of a sub-chunk element-per-lane: v[k] = element 64 k + lane (0 behind n)
+__device__ __forceinline__ void load16_global(cgptr src, uint32_t n, uint32_t (&v)[16], int lane)
+{
+  // (one per-lane offset, the steps as immediate offsets of the loads; the lanes behind n in the last
+  // step read element n - 1 again: in bounds, and not used by anything)
+  const HC_GLOBAL uint32_t* p = reinterpret_cast<const HC_GLOBAL uint32_t*>(src) + lane;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    v[k] = 0;
+    if (64u * k + 64u <= n) // (wave-uniform)
+      v[k] = p[64 * k];
+    else if (64u * k < n)
+      v[k] = reinterpret_cast<const HC_GLOBAL uint32_t*>(src)[min(64u * k + (uint32_t)lane, n - 1u)];
+  }
+}
+__device__ __forceinline__ void load16_lds(const uint8_t* X, uint32_t n, uint32_t (&v)[16], int lane)
+{
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    v[k] = 0;
+    if (64u * k < n)
+      v[k] = *reinterpret_cast<const uint32_t*>(X + x4_addr(64u * k + (uint32_t)lane)); // (behind n: whatever lies there, in bounds)
+  }
+}
+
+// v[k] <- element i + 1 minus element i (i = 64 k + lane): the delta layer on n >= 1 elements in
+// registers (reference block_delta_compress :317-328); what lands at and behind n - 1 is not used.
+__device__ __forceinline__ void delta16(uint32_t (&v)[16], uint32_t n)
+{
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (64u * k < n) {
+      const uint32_t first_above = k + 1 < 16 ? read_lane(v[(k + 1) % 16], 0) : 0u;
+      v[k] = from_lane_above(v[k], first_above) - v[k];
+    }
+  }
+}
+
+// the array in registers -> LDS (padded), n elements, with the tail up to a multiple of 32 filled
+// with copies of the last element (the packer takes whole blocks of 32: a copy does not move
+// minimum or maximum, and the bits behind n are masked off)
+__device__ __forceinline__ void store16_lds(uint8_t* X, uint32_t n, const uint32_t (&v)[16], int lane)
+{
+  uint32_t last = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (64u * k < n) {
+      const uint32_t i = 64u * k + (uint32_t)lane;
+      if (i < n)
+        *reinterpret_cast<uint32_t*>(X + x4_addr(i)) = v[k];
+      if (64u * k + 64u >= n)
+        last = read_lane(v[k], (int)((n - 1u) & 63u));
+    }
+  }
+  const uint32_t fill = (32u - (n & 31u)) & 31u;
+  if ((uint32_t)lane < fill)
+    *reinterpret_cast<uint32_t*>(X + x4_addr(n + (uint32_t)lane)) = last;
+}
+
+// RLE of the n elements in v (reference block_rle_compress :124-241): the values of the runs to
+// X[0 .. m), the positions behind their last elements to Eb[0 .. m) (padded layouts), both filled
+// up to a multiple of 32 entries for the packer (values: copies of the last one; ends: going on at
+// the last run's length).  Returns m.
+__device__ __forceinline__ uint32_t rle16(const uint32_t (&v)[16], uint32_t n, uint8_t* X, uint8_t* Eb, int lane)
+{
+  uint32_t m = 0, last = 0;
+  // the run ends of a step: value and end position to consecutive ranks
+  auto emit = [&](bool f, uint32_t cur, uint32_t end_pos) {
+    const uint64_t ends = wave_ballot(f);
+    if (f) {
+      const uint32_t rank = lanes_below_me(ends, m);
+      const uint32_t pad4 = (rank >> 3) & ~3u; // 4 (rank / 32): the padding in front of the rank's block
+      *reinterpret_cast<uint32_t*>(X + ((rank << 2) + pad4)) = cur;
+      *reinterpret_cast<uint16_t*>(Eb + ((rank << 1) + pad4)) = (uint16_t)end_pos;
+    }
+    m += (uint32_t)__builtin_popcountll(ends);
+  };
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (64u * k + 64u < n) { // (wave-uniform) a full step: every element has a right neighbour
+      const uint32_t cur = v[k];
+      const uint32_t nx = from_lane_above(cur, read_lane(v[(k + 1) % 16], 0));
+      emit(cur != nx, cur, 64u * k + 1u + (uint32_t)lane);
+    } else if (64u * k < n) { // the last step: the last element ends a run whatever follows
+      const uint32_t cur = v[k];
+      const uint32_t nx = from_lane_above(cur, 0u);
+      const uint32_t i1 = 64u * k + 1u + (uint32_t)lane;
+      last = read_lane(cur, (int)((n - 1u) & 63u));
+      emit((i1 < n && cur != nx) || i1 == n, cur, i1);
+    }
+  }
+  const uint32_t fill = (32u - (m & 31u)) & 31u;
+  if (fill != 0) { // (m >= 1 here: n >= 1)
+    lds_lane_exchange_fence();
+    uint32_t before = 0;
+    if (m >= 2)
+      before = uniform((uint32_t)*reinterpret_cast<const uint16_t*>(Eb + e4_addr(m - 2u)));
+    lds_lane_exchange_fence();
+    if ((uint32_t)lane < fill) {
+      *reinterpret_cast<uint32_t*>(X + x4_addr(m + (uint32_t)lane)) = last;
+      *reinterpret_cast<uint16_t*>(Eb + e4_addr(m + (uint32_t)lane)) = (uint16_t)(n + ((uint32_t)lane + 1u) * (n - before));
+    }
+  }
+  lds_lane_exchange_fence();
+  return m;
+}
+
+// y[0 .. 32) of BW bits each -> BW words, LSB first (reference block_bitpack :523-552), all shifts
+// known at compile time: one v_lshl_or_b32 per element, a second instruction where an element
+// straddles two words.  The words go to data[w0 .. w0 + BW): all of them at once from a lane whose
+// block lies wholly inside the array (`whole`), else word by word up to `words`, the array's last
+// word without the bits of the fill behind its last element (`last_mask`).
+template <int BW, class Get>
+__device__ __forceinline__ void pack32_store(
+    Get get, HC_GLOBAL uint32_t* data, uint32_t w0, uint32_t mine, uint32_t last_at, uint32_t last_mask)
+{
+  uint32_t w[BW];
+#pragma unroll
+  for (int j = 0; j < BW; ++j)
+    w[j] = 0;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const int p = k * BW, word = p >> 5, sh = p & 31;
+    const uint32_t yk = get(k);
+    w[word % BW] |= yk << sh;
+    if (sh + BW > 32)
+      w[(word + 1) % BW] |= yk >> (32 - sh);
+  }
+  // `mine` of my BW words lie inside the array; word `last_at` of mine (if it is one of them) is the
+  // array's last and loses the bits of the fill behind its last element
+#pragma unroll
+  for (int j = 0; j < BW; ++j)
+    if ((uint32_t)j < mine)
+      data[w0 + j] = (uint32_t)j == last_at ? w[j] & last_mask : w[j];
+}
+
+// One array of the sub-chunk to HBM (reference block_write :646-680 / get_for_bitwidth :394-471 /
+// block_bitpack) from the padded LDS layouts.  LENGTHS: the run lengths (16-bit elements), taken
+// as differences of the run ends in Eb; else the 32-bit elements in X.  n elements (the arrays are
+// filled to a multiple of 32, see rle16 / store16_lds).  Returns the byte length the format
+// records, 0xFFFFFFFF when the array does not fit (reference :668-671).
+template <bool LENGTHS>
+__device__ __forceinline__ uint32_t write_array4(
+    gptr out, uint32_t off, uint32_t limit, const uint8_t* X, const uint8_t* Eb, uint32_t n, int bp, int lane)
+{
+  constexpr uint32_t ES = LENGTHS ? 2 : 4;
+  HC_GLOBAL uint32_t* dst = reinterpret_cast<HC_GLOBAL uint32_t*>(out + off);
+  // my 32 elements: block min(lane, last block) -- the lanes behind the array look at its last
+  // block again, which moves neither minimum nor maximum, and store nothing
+  const uint32_t blocks = (n + 31u) >> 5;
+  const uint32_t tb = blocks == 0 ? 0u : min((uint32_t)lane, blocks - 1u);
+  uint32_t y[32];
+  uint32_t bw = 8 * ES; // (a raw array is its elements at their full width, no frame of reference)
+  uint32_t fr = 0;
+  if (LENGTHS) {
+    // run lengths = differences of the run ends, two at a time (16-bit halves): pair q = {end 2q, end 2q + 1}
+    // minus {end 2q - 1, end 2q}
+    const uint8_t* p = Eb + tb * 68u;
+    uint32_t e[16], len2[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      e[q] = *reinterpret_cast<const uint32_t*>(p + 4 * q);
+    // the run end in front of my block: the last one of the block below (block 0: 0); its entry
+    // lies at - 6 (the dword at - 4 is padding)
+    uint32_t below = tb == 0 ? 0u : (uint32_t)*reinterpret_cast<const uint16_t*>(p - 6) << 16;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const uint32_t shifted = __builtin_amdgcn_alignbit(e[q], below, 16); // {hi of the pair below, my lo}
+      typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+      const u16x2 d = __builtin_bit_cast(u16x2, e[q]) - __builtin_bit_cast(u16x2, shifted);
+      len2[q] = __builtin_bit_cast(uint32_t, d);
+      below = e[q];
+    }
+    if (bp) {
+      // frame of reference = the smallest length, bit width from largest - smallest (reference
+      // get_for_bitwidth :394-471; lengths are 1 .. 1024: the same signed or not)
+      typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+      u16x2 mn2 = __builtin_bit_cast(u16x2, len2[0]), mx2 = mn2;
+#pragma unroll
+      for (int q = 1; q < 16; ++q) {
+        const u16x2 x = __builtin_bit_cast(u16x2, len2[q]);
+        mn2 = __builtin_elementwise_min(mn2, x);
+        mx2 = __builtin_elementwise_max(mx2, x);
+      }
+      int32_t mn = 0, mx = 0;
+      if (n > 0) {
+        mn = wave_min_i32((int32_t)min((uint32_t)mn2.x, (uint32_t)mn2.y));
+        mx = wave_max_i32((int32_t)max((uint32_t)mx2.x, (uint32_t)mx2.y));
+      }
+      const uint32_t range = (uint32_t)(mx - mn);
+      bw = range ? 32u - (uint32_t)__builtin_clz(range) : 0u;
+      fr = (uint32_t)mn;
+      const uint32_t fr2 = fr | (fr << 16);
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        len2[q] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, len2[q]) - __builtin_bit_cast(u16x2, fr2));
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      y[q] = len2[q]; // (two lengths per register)
+  } else {
+    const uint8_t* p = X + tb * 132u;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      y[k] = *reinterpret_cast<const uint32_t*>(p + 4 * k);
+    if (bp) {
+      // frame of reference = minimum under the SIGNED interpretation, bit width from max - min
+      int32_t mn = 0, mx = 0;
+      if (n > 0) {
+        mn = (int32_t)y[0];
+        mx = mn;
+#pragma unroll
+        for (int k = 1; k < 32; ++k) {
+          const int32_t x = (int32_t)y[k];
+          mn = x < mn ? x : mn;
+          mx = x > mx ? x : mx;
+        }
+        mn = wave_min_i32(mn);
+        mx = wave_max_i32(mx);
+      }
+      const uint32_t range = (uint32_t)mx - (uint32_t)mn;
+      bw = range ? 32u - (uint32_t)__builtin_clz(range) : 0u;
+      fr = (uint32_t)mn;
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        y[k] -= fr;
+    }
+  }
+  const uint32_t bits = n * bw;
+  const uint32_t words = (bits + 31u) >> 5;
+  const uint32_t ob = bp ? 8u + 4u * words : n * ES;
+  if (off + (bp ? ob : 4u * words) > limit)
+    return 0xFFFFFFFFu;
+  if (bp && lane == 0) {
+    // [FOR][pad to 4][bitwidth<<16 | n]; pads written as 0
+    dst[0] = LENGTHS ? (fr & 0xFFFFu) : fr;
+    dst[1] = (bw << 16) | n;
+  }
+  if (words == 0 || (uint32_t)lane >= blocks)
+    return ob;
+  HC_GLOBAL uint32_t* data = dst + (bp ? 2 : 0);
+  // my words: [lane bw, lane bw + bw) of the array; the last word of the array holds no bit of the fill
+  const uint32_t tail = bits & 31u;
+  const uint32_t last_mask = tail ? (1u << tail) - 1u : ~0u;
+  const uint32_t w0 = (uint32_t)lane * bw;
+  const uint32_t mine = min(words - min(w0, words), bw); // how many of my bw words lie inside the array
+  const uint32_t last_at = words - 1u - w0;              // (which of mine is the array's last word, if any)
+  auto get = [&](int k) -> uint32_t { return LENGTHS ? (y[(k / 2) % 32] >> (16 * (k & 1))) & 0xFFFFu : y[k % 32]; };
+  switch (bw) {
+#define HC_CASE(B) case B: pack32_store<B>(get, data, w0, mine, last_at, last_mask); break;
+    HC_CASE(1) HC_CASE(2) HC_CASE(3) HC_CASE(4) HC_CASE(5) HC_CASE(6) HC_CASE(7) HC_CASE(8)
+    HC_CASE(9) HC_CASE(10) HC_CASE(11) HC_CASE(12) HC_CASE(13) HC_CASE(14) HC_CASE(15) HC_CASE(16)
+    HC_CASE(32)
+#undef HC_CASE
+  default: {
+    // the bit widths 17 .. 31 (columns that hardly compress): the same with the shifts in scalar registers
+    uint64_t acc = 0;
+    uint32_t sh = 0, wi = w0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      acc |= (uint64_t)get(k) << sh;
+      sh += bw;
+      if (sh >= 32u) { // (wave-uniform; once per element at these widths)
+        if (wi < words)
+          data[wi] = wi + 1u == words ? (uint32_t)acc & last_mask : (uint32_t)acc;
+        ++wi;
+        acc >>= 32;
+        sh -= 32u;
+      }
+    }
+  } break;
+  }
+  return ob;
+}
+
+// (launch bound: HC_CASC_OCC waves per SIMD; LDS allows 25 one-wave workgroups per CU)
+#ifndef HC_CASC_OCC
+#define HC_CASC_OCC 6
+#endif
+template <int S>
+__global__ __launch_bounds__(kWave * kWavesPerBlock, HC_CASC_OCC) void cascaded_compress_kernel(
     const uint8_t* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes_arr,
     uint8_t* const* __restrict__ out_ptrs,
@@ -271,17 +753,20 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
     const int R, const int D, const int bp)
 {
   typedef typename UIntOf<S>::type UT;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // kWavesPerBlock * wave_lds_bytes<S, CB>()
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // kWavesPerBlock * wave_lds_bytes<S>()
   const int lane = lane_id();
   // everything that steers the layers is wave-uniform: say so (see uniform())
   const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
   const size_t part = (size_t)blockIdx.x * kWavesPerBlock + wave;
   if (part >= batch)
     return;
-  uint8_t* my = smem + wave * wave_lds_bytes<S, CB>();
+  uint8_t* my = smem + wave * wave_lds_bytes<S>();
   UT* bufA = reinterpret_cast<UT*>(my);
-  uint16_t* cnts = reinterpret_cast<uint16_t*>(my + elem_buf_bytes<CB>());
-  uint32_t* meta = reinterpret_cast<uint32_t*>(my + elem_buf_bytes<CB>() + (CB / S) * 2);
+  uint16_t* cnts = reinterpret_cast<uint16_t*>(my + enc_buf_bytes());                       // (the generic path's layout)
+  uint32_t* meta = reinterpret_cast<uint32_t*>(my + enc_buf_bytes() + (CB / S) * 2);
+  (void)bufA;
+  (void)cnts;
+  (void)meta;
 
   cgptr in = to_global(uniform_ptr(in_ptrs[part]));
   const size_t in_bytes64 = uniform((uint64_t)in_bytes_arr[part]);
@@ -302,6 +787,75 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
   const uint32_t dh_off = ru((uint32_t)(4 + 4 * (R + 1)), (uint32_t)S);
   const int layers = R > D ? R : D;
 
+  if constexpr (S == 4) {
+    // ---- the fast path (see rle16 / write_array4 above)
+    static_assert(kWavesPerBlock == 1 || true, "");
+    uint8_t* const X = my;
+    uint8_t* const Eb = my + kX4Bytes;
+    for (uint32_t c = 0; c < nchunks && use; ++c) {
+      const uint32_t chunk_start = cur;
+      cur += msz;
+      uint32_t n = min(N - c * CE, CE);
+      uint32_t img = 0; // the chunk metadata image: lane j holds its word j (reference :1004-1014)
+      uint32_t v[16];
+      load16_global(in + (size_t)c * CB, n, v, lane);
+      bool in_regs = true; // the array the next layer works on is in v (else: in X)
+      int rr = R, dr = D;
+      for (int l = 0; l < layers && use; ++l) {
+        if (rr > 0) { // reference :913-953
+          if (!in_regs)
+            load16_lds(X, n, v, lane);
+          const uint32_t m = rle16(v, n, X, Eb, lane);
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            v[k] = 0; // (the registers are free from here on: what comes next loads its own)
+          const uint32_t ob = write_array4<true>(out, cur, limit, X, Eb, m, bp, lane);
+          if (ob == 0xFFFFFFFFu) {
+            use = false;
+            break;
+          }
+          cur += ru(ob, 4);
+          img = lane == R - rr + 1 ? ob : img;
+          n = m;
+          --rr;
+          in_regs = false;
+        }
+        if (dr > 0) { // reference :955-977
+          if (n == 0) { // undefined in the reference (:323); raw fallback here
+            use = false;
+            break;
+          }
+          if (!in_regs)
+            load16_lds(X, n, v, lane);
+          const uint32_t head = read_lane(v[0], 0);
+          img = lane == (int)(dh_off / 4) + (D - dr) ? head : img;
+          delta16(v, n);
+          n -= 1;
+          --dr;
+          in_regs = true;
+        }
+      }
+      if (!use)
+        break;
+      if (in_regs)
+        store16_lds(X, n, v, lane);
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        v[k] = 0;
+      lds_lane_exchange_fence();
+      const uint32_t ob = write_array4<false>(out, cur, limit, X, Eb, n, bp, lane); // (reference :983-984: 4-byte elements need no alignment gap)
+      if (ob == 0xFFFFFFFFu) {
+        use = false;
+        break;
+      }
+      cur += ru(ob, 4); // reference :999-1001
+      img = lane == 0 ? cur - chunk_start : img;
+      img = lane == R + 1 ? ob : img;
+      // flush the chunk metadata image (reference :1004-1014)
+      if ((uint32_t)lane < msz / 4)
+        reinterpret_cast<HC_GLOBAL uint32_t*>(out + chunk_start)[lane] = img;
+    }
+  } else
   for (uint32_t c = 0; c < nchunks && use; ++c) {
     const uint32_t chunk_start = cur;
     cur += msz;
@@ -310,7 +864,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
     {
       cgptr src = in + (size_t)c * CB;
       const uint32_t nb = n * S;
-      uint32_t* dstw = reinterpret_cast<uint32_t*>(bufA);
       for (uint32_t o = (uint32_t)lane * 16u; o < nb; o += kWave * 16u) {
         if (o + 16 <= nb) {
           const u32x4 q = load_u128_any(src + o);
@@ -320,19 +873,18 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
             reinterpret_cast<uint8_t*>(bufA)[k] = src[k];
         }
       }
-      (void)dstw;
       if (lane < 16)
         meta[lane] = 0;
     }
-    // Both layers work in place: a step reads elements [base, base + 64] and
-    // then writes at or below base + 63 (RLE compacts, delta keeps the
-    // index), LDS operations of a wave execute in order, and within a step
-    // every lane's loads precede every lane's store.
+    // Both layers work in place: a round reads its elements and one more and
+    // then writes at or below them (RLE compacts, delta keeps the index), LDS
+    // operations of a wave execute in order, and within a round every lane's
+    // loads precede every lane's store.
     UT* const x = bufA;
     int rr = R, dr = D;
     for (int l = 0; l < layers && use; ++l) {
       if (rr > 0) { // reference :913-953
-        const uint32_t m = wave_rle<UT>(x, n, x, cnts, lane);
+        const uint32_t m = wave_rle<UT>(x, n, cnts, lane);
         const uint32_t ob = wave_write_array<uint16_t>(out, cur, limit, cnts, m, bp, lane);
         if (ob == 0xFFFFFFFFu) {
           use = false;
@@ -351,11 +903,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
         }
         if (lane == 0)
           *reinterpret_cast<UT*>(reinterpret_cast<uint8_t*>(meta) + dh_off + (D - dr) * S) = x[0];
-        for (uint32_t i = (uint32_t)lane; i + 1 < n; i += kWave) {
-          const UT hi = x[i + 1], lo = x[i];
-          lds_lane_exchange_fence();
-          x[i] = (UT)(hi - lo);
-        }
+        lds_lane_exchange_fence();
+        wave_delta<UT>(x, n, lane);
         n -= 1;
         --dr;
       }
@@ -396,8 +945,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void cascaded_compress_kern
     total = raw + ru(nb, 4);
   }
   if (lane == 0) {
-    constexpr uint32_t kCode = CB == 8192 ? 1u : CB == 16384 ? 2u : 0u; // sub-chunk size (see the head of the file)
-    const uint32_t h = use ? ((uint32_t)R | ((uint32_t)D << 8) | (((uint32_t)bp | (kCode << 4)) << 16)) : 0u;
+    const uint32_t h = use ? ((uint32_t)R | ((uint32_t)D << 8) | ((uint32_t)bp << 16)) : 0u;
     reinterpret_cast<HC_GLOBAL uint32_t*>(out)[0] = h | ((uint32_t)type_tag << 24);
     reinterpret_cast<HC_GLOBAL uint32_t*>(out)[1] = N * S;
     out_bytes_arr[part] = total;
@@ -533,13 +1081,50 @@ __device__ __forceinline__ int wave_read_array(
                           max_elems, lane);
 }
 
-template <int S, int CB>
+// ---- the blocked passes of the decoder --------------------------------------
+// E values of a round per lane -> the running sum in front of each of them (an exclusive prefix
+// over the whole array, `carry` = the sum in front of the round), stored one element on: y[pos0 + k + 1]
+// = carry + v[0 .. k] summed, and y[first element of the round] = carry by lane 0.  In registers that
+// is a shift by one element: what lane t stores at y[pos0 + k] is the sum up to its own element k - 1,
+// or for k = 0 the lane below's last one (one DPP move), so every lane stores an aligned block.
+// Returns the new carry.  `store`: the lanes whose block (elements pos0 .. pos0 + E - 1 of y) is wanted.
+template <typename UT>
+__device__ __forceinline__ UT prefix_store_shifted(
+    UT (&v)[Blocked<sizeof(UT)>::E], UT carry, UT* y, uint32_t pos0, bool store, int lane)
+{
+  constexpr int S = sizeof(UT), E = Blocked<S>::E;
+#pragma unroll
+  for (int k = 1; k < E; ++k)
+    v[k] = (UT)(v[k] + v[k - 1]); // inclusive, inside the lane
+  UT incl;
+  if (S > 4)
+    incl = (UT)wave_scan_add_u64((uint64_t)v[E - 1]);
+  else
+    incl = (UT)wave_scan_add_u32((uint32_t)v[E - 1]);
+  const UT base = (UT)(carry + incl - v[E - 1]); // the sum in front of my block
+  typedef typename std::conditional<(S > 4), uint64_t, uint32_t>::type WT;
+  UT s[E];
+  s[0] = (UT)from_lane_below((WT)(UT)(base + v[E - 1]), (WT)carry, lane);
+#pragma unroll
+  for (int k = 1; k < E; ++k)
+    s[k] = (UT)(base + v[k - 1]);
+  if (store)
+    store_block(y + pos0, s);
+  UT total;
+  if (S > 4)
+    total = (UT)((uint64_t)read_lane((uint32_t)((uint64_t)incl), 63) | ((uint64_t)read_lane((uint32_t)((uint64_t)incl >> 32), 63) << 32));
+  else
+    total = (UT)read_lane((uint32_t)incl, 63);
+  return (UT)(carry + total);
+}
+
+template <int S>
 __device__ __forceinline__ void cascaded_decode_partition(
     const uint8_t* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes_arr,
     const size_t* __restrict__ out_caps, uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
     hipcompStatus_t* __restrict__ statuses, const size_t part, uint8_t* const smem, const int lane);
 
-template <int S, int CB>
+template <int S>
 __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
     const uint8_t* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes_arr,
@@ -547,12 +1132,11 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
     uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
     hipcompStatus_t* __restrict__ statuses)
 {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // dec_lds_bytes<S, CB>()
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // dec_lds_bytes<S>()
   const int lane = lane_id();
-  // Each width and sub-chunk size has its own launch (the LDS a wave needs
-  // depends on both); a partition is handled by the launch that matches ITS
-  // type byte (the reference dispatches on partition 0 only) and ITS sub-chunk
-  // code.  Undecodable headers are reported by the 1-byte 4096 launch.
+  // Each width has its own launch (the LDS a wave needs depends on it); a partition is
+  // handled by the launch that matches ITS type byte (the reference dispatches on
+  // partition 0 only).  Undecodable headers are reported by the 1-byte launch.
   // A launch is a fixed number of waves (as many as its LDS lets the chip
   // hold); wave w takes partitions w, w + waves, ...  The headers of the next
   // 64 of them are looked at together, one per lane, so that a launch with
@@ -565,37 +1149,37 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
       cgptr comp = to_global(comp_ptrs[p]);
       const bool bad_header = comp == nullptr || comp_bytes_arr[p] < kPartMeta;
       const uint32_t type = bad_header ? 0xFFu : (uint32_t)comp[3];
-      const uint32_t code = bad_header ? 0u : (uint32_t)comp[2] >> 4;
-      constexpr uint32_t kCode = CB == 8192 ? 1u : CB == 16384 ? 2u : 0u;
-      mine = (bad_header || type > 7 || code > 2)
-                 ? (S == 1 && kCode == 0)
-                 : (code == kCode
-                    && ((S == 1 && type <= 1) || (S == 2 && (type == 2 || type == 3))
-                        || (S == 4 && (type == 4 || type == 5)) || (S == 8 && (type == 6 || type == 7))));
+      mine = (bad_header || type > 7)
+                 ? S == 1
+                 : ((S == 1 && type <= 1) || (S == 2 && (type == 2 || type == 3))
+                    || (S == 4 && (type == 4 || type == 5)) || (S == 8 && (type == 6 || type == 7)));
     }
     for (uint64_t todo = wave_ballot(mine); todo != 0; todo &= todo - 1)
-      cascaded_decode_partition<S, CB>(comp_ptrs, comp_bytes_arr, out_caps, out_ptrs, actual_bytes, statuses,
-                                       first + (size_t)__builtin_ctzll(todo) * waves, smem, lane);
+      cascaded_decode_partition<S>(comp_ptrs, comp_bytes_arr, out_caps, out_ptrs, actual_bytes, statuses,
+                                   first + (size_t)__builtin_ctzll(todo) * waves, smem, lane);
   }
 }
 
-// One partition, by one wave (the launch that owns its width and sub-chunk size).
-template <int S, int CB>
+// One partition, by one wave (the launch that owns its width).
+template <int S>
 __device__ __forceinline__ void cascaded_decode_partition(
     const uint8_t* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes_arr,
     const size_t* __restrict__ out_caps, uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
     hipcompStatus_t* __restrict__ statuses, const size_t part, uint8_t* const smem, const int lane)
 {
   typedef typename UIntOf<S>::type UT;
+  constexpr int E = Blocked<S>::E;
   cgptr comp = to_global(uniform_ptr(comp_ptrs[part]));
   const size_t comp_bytes64 = uniform((uint64_t)comp_bytes_arr[part]);
   const bool bad_header = comp == nullptr || comp_bytes64 < kPartMeta;
-  uint32_t type = 0xFFu, code = 0;
+  uint32_t type = 0xFFu, byte2 = 0;
   if (!bad_header) {
     type = uniform((uint32_t)comp[3]);
-    code = uniform((uint32_t)comp[2]) >> 4;
+    byte2 = uniform((uint32_t)comp[2]);
   }
-  const bool undecodable = bad_header || type > 7 || code > 2;
+  // (byte 2 is use_bp, 0 or 1; a high nibble marked the larger sub-chunks of rounds 2-3, an extension
+  // that is gone: such a stream is not decodable)
+  const bool undecodable = bad_header || type > 7 || (byte2 >> 4) != 0;
   auto finish = [&](bool ok, uint32_t bytes) {
     if (lane == 0) {
       actual_bytes[part] = ok ? bytes : 0;
@@ -632,9 +1216,9 @@ __device__ __forceinline__ void cascaded_decode_partition(
   }
   uint8_t* my = smem;
   UT* bufA = reinterpret_cast<UT*>(my);
-  UT* bufB = reinterpret_cast<UT*>(my + elem_buf_bytes<CB>());
-  uint16_t* marks = reinterpret_cast<uint16_t*>(my + 2 * elem_buf_bytes<CB>());
-  uint32_t* stage = reinterpret_cast<uint32_t*>(my + 2 * elem_buf_bytes<CB>() + (CB / S) * 2);
+  UT* bufB = reinterpret_cast<UT*>(my + dec_buf_bytes());
+  uint16_t* marks = reinterpret_cast<uint16_t*>(my + 2 * dec_buf_bytes());
+  uint32_t* stage = reinterpret_cast<uint32_t*>(my + 2 * dec_buf_bytes() + (CB / S) * 2);
   const uint32_t* meta = stage; // the chunk metadata is the head of the staged image
 
   constexpr uint32_t CE = CB / S;
@@ -643,14 +1227,14 @@ __device__ __forceinline__ void cascaded_decode_partition(
   const int layers = R > D ? R : D;
   uint32_t pos = ru(kPartMeta, S), done = 0;
   bool ok = true;
-  // stage_words<CB>() words of the sub-chunk at `p`, stage_per_lane<CB>() per lane, clipped to the
+  // kStageWords words of the sub-chunk at `p`, kStagePerLane per lane, clipped to the
   // partition (words past the end read as 0); issued one sub-chunk ahead
-  uint32_t pf[stage_per_lane<CB>()];
+  uint32_t pf[kStagePerLane];
   auto prefetch = [&](uint32_t p) {
     const HC_GLOBAL uint32_t* w = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + p);
     const uint32_t avail = end_w - p / 4;
 #pragma unroll
-    for (int k = 0; k < (int)stage_per_lane<CB>(); ++k) {
+    for (int k = 0; k < (int)kStagePerLane; ++k) {
       const uint32_t idx = (uint32_t)lane + (uint32_t)k * kWave;
       pf[k] = w[min(idx, avail - 1)];
     }
@@ -663,7 +1247,7 @@ __device__ __forceinline__ void cascaded_decode_partition(
       break;
     }
 #pragma unroll
-    for (int k = 0; k < (int)stage_per_lane<CB>(); ++k)
+    for (int k = 0; k < (int)kStagePerLane; ++k)
       stage[lane + k * kWave] = pf[k];
     const uint32_t csz = uniform(meta[0]);
     // A sub-chunk has to lie inside the partition and to move the cursor on:
@@ -689,7 +1273,7 @@ __device__ __forceinline__ void cascaded_decode_partition(
     }
     UT* x = bufA;
     UT* y = bufB;
-    int n = wave_read_array<UT, stage_words<CB>()>(comp, end_w, pos, msz + offs_final, uniform(meta[1 + R]), bp, stage, x, CE, lane);
+    int n = wave_read_array<UT, kStageWords>(comp, end_w, pos, msz + offs_final, uniform(meta[1 + R]), bp, stage, x, CE, lane);
     if (n < 0) {
       ok = false;
       break;
@@ -707,28 +1291,15 @@ __device__ __forceinline__ void cascaded_decode_partition(
           ok = false;
           break;
         }
+        // y[0] = head, y[i + 1] = y[i] + x[i]: n + 1 elements (blocked: prefix_store_shifted)
         UT carry = *reinterpret_cast<const UT*>(reinterpret_cast<const uint8_t*>(meta) + dh_off + l * S);
-
-        for (uint32_t b0 = 0; b0 < (uint32_t)n; b0 += kWave) {
-          const uint32_t i = b0 + (uint32_t)lane;
-          const UT own = i < (uint32_t)n ? x[i] : (UT)0;
-          UT incl;
-          if (S > 4)
-            incl = (UT)wave_scan_add_u64((uint64_t)own);
-          else
-            incl = (UT)wave_scan_add_u32((uint32_t)own);
-          if (i < (uint32_t)n)
-            y[i] = (UT)(carry + incl - own);
-          if (S > 4) {
-            const uint64_t tot = (uint64_t)read_lane((uint32_t)((uint64_t)incl), 63)
-                                 | ((uint64_t)read_lane((uint32_t)((uint64_t)incl >> 32), 63) << 32);
-            carry = (UT)(carry + (UT)tot);
-          } else {
-            carry = (UT)(carry + (UT)read_lane((uint32_t)incl, 63));
-          }
+        for (uint32_t b0 = 0; b0 <= (uint32_t)n; b0 += Blocked<S>::ROUND) {
+          const uint32_t pos0 = b0 + (uint32_t)lane * E;
+          UT v[E];
+          load_block(x + min(pos0, CE - (uint32_t)E), v); // (what lies at and behind n takes no part in what is used)
+          carry = prefix_store_shifted<UT>(v, carry, y, pos0, pos0 <= (uint32_t)n, lane);
         }
-        if (lane == 0)
-          y[n] = carry;
+        lds_lane_exchange_fence();
         UT* t = x; x = y; y = t;
         ++n;
       }
@@ -771,7 +1342,7 @@ __device__ __forceinline__ void cascaded_decode_partition(
           const uint32_t off = pos + rel;
           bool good = !((off & 3u) || (off + ru(nbytes, 4)) / 4 > end_w);
           if (good) {
-            if (rel + ru(nbytes, 4) <= stage_words<CB>() * 4)
+            if (rel + ru(nbytes, 4) <= kStageWords * 4)
               good = run_starts(static_cast<const uint32_t*>(stage + rel / 4));
             else
               good = run_starts(reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off));
@@ -799,42 +1370,73 @@ __device__ __forceinline__ void cascaded_decode_partition(
         UT head = 0;
         if (with_delta)
           head = *reinterpret_cast<const UT*>(reinterpret_cast<const uint8_t*>(meta) + dh_off + (l - 1) * S);
-        HC_GLOBAL UT* gdst = reinterpret_cast<HC_GLOBAL UT*>(out + (size_t)done * S);
-        uint32_t run_carry = 0;
+        gptr gdst = out + (size_t)done * S;
+        // The expansion, blocked: a lane takes E consecutive output elements -- their markers (one or
+        // two 16-byte reads), the running maximum inside the lane on top of the maximum of the lanes
+        // below (one wave scan), the values of those runs (E reads), and then either the prefix sum of
+        // the delta layer that follows (prefix_store_shifted) or the block as it is, to LDS or to HBM.
+        // (n >= 1 here whenever total > 0: run 1 starts at element 0, so the maximum is never 0 inside `total`.)
+        uint32_t run_carry = 1; // (>= 1: the lanes behind `total` then read x[0], not x[-1])
         UT sum_carry = head;
-        for (uint32_t b0 = 0; b0 < total; b0 += kWave) {
-          const uint32_t j = b0 + (uint32_t)lane;
-          const uint32_t mk = j < total ? marks[j] : 0u;
-          uint32_t r = wave_scan_max_u32(mk);
-          r = r > run_carry ? r : run_carry;
-          run_carry = read_lane(r, 63);
-          UT v = j < total ? x[r - 1] : (UT)0;
-          if (with_delta) {
-            UT incl;
-            if (S > 4) {
-              incl = (UT)wave_scan_add_u64((uint64_t)v);
-              const uint64_t tot = (uint64_t)read_lane((uint32_t)((uint64_t)incl), 63)
-                                   | ((uint64_t)read_lane((uint32_t)((uint64_t)incl >> 32), 63) << 32);
-              v = (UT)(sum_carry + incl);
-              sum_carry = (UT)(sum_carry + (UT)tot);
-            } else {
-              incl = (UT)wave_scan_add_u32((uint32_t)v);
-              v = (UT)(sum_carry + incl);
-              sum_carry = (UT)(sum_carry + (UT)read_lane((uint32_t)incl, 63));
+        const uint32_t reach = with_delta ? total + 1 : total; // elements of y that are wanted
+        for (uint32_t b0 = 0; b0 < reach; b0 += Blocked<S>::ROUND) {
+          const uint32_t pos0 = b0 + (uint32_t)lane * E;
+          uint32_t mk[E];
+          {
+            const u32x4* mp = reinterpret_cast<const u32x4*>(marks + min(pos0, CE - (uint32_t)E));
+            uint32_t w[E / 2];
+#pragma unroll
+            for (int i = 0; i < E / 8; ++i) {
+              const u32x4 t = mp[i];
+              w[4 * i] = t.x;
+              w[4 * i + 1] = t.y;
+              w[4 * i + 2] = t.z;
+              w[4 * i + 3] = t.w;
             }
-            if (j < total)
-              y[j + 1] = v;
+#pragma unroll
+            for (int k = 0; k < E; ++k)
+              mk[k] = (k & 1) ? w[(k / 2) % (E / 2)] >> 16 : w[(k / 2) % (E / 2)] & 0xFFFFu;
+          }
+          // (a lane whose block begins at or behind `total` has nothing there: its markers do not count)
+          const bool has = pos0 < total;
+          uint32_t r[E];
+          r[0] = has ? mk[0] : 0u;
+#pragma unroll
+          for (int k = 1; k < E; ++k)
+            r[k] = max(r[k - 1], has ? mk[k] : 0u);
+          const uint32_t upto = wave_scan_max_u32(r[E - 1]);
+          const uint32_t below = max(run_carry, dpp_u32<0x138, 0xF>(upto)); // the run in force at my first element
+          run_carry = max(run_carry, read_lane(upto, 63));
+          UT v[E];
+#pragma unroll
+          for (int k = 0; k < E; ++k)
+            v[k] = x[max(r[k], below) - 1u];
+          if (with_delta) {
+            sum_carry = prefix_store_shifted<UT>(v, sum_carry, y, pos0, pos0 <= total, lane);
           } else if (to_hbm) {
-            if (j < total)
-              gdst[j] = v;
+            if (pos0 + (uint32_t)E <= total) {
+              uint32_t w[Blocked<S>::W];
+#pragma unroll
+              for (int i = 0; i < Blocked<S>::W; ++i)
+                w[i] = S == 8 ? (uint32_t)((uint64_t)v[(i / 2) % E] >> (32 * (i & 1))) : (uint32_t)v[i % E];
+#pragma unroll
+              for (int i = 0; i < Blocked<S>::W / 4; ++i) {
+                u32x4 t = {w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+                *reinterpret_cast<HC_GLOBAL u32x4_unaligned*>(gdst + (size_t)pos0 * S + 16u * i) = t;
+              }
+            } else if (pos0 < total) {
+#pragma unroll
+              for (int k = 0; k < E; ++k)
+                if (pos0 + (uint32_t)k < total)
+                  reinterpret_cast<HC_GLOBAL UT*>(gdst)[pos0 + k] = v[k];
+            }
           } else {
-            if (j < total)
-              y[j] = v;
+            if (pos0 < total)
+              store_block(y + pos0, v);
           }
         }
+        lds_lane_exchange_fence();
         if (with_delta) {
-          if (lane == 0)
-            y[0] = head;
           fused_delta = l - 1;
           n = (int)total + 1;
         } else {
@@ -898,28 +1500,13 @@ typedef void (*DecompressKernel)(
     const uint8_t* const*, const size_t*, const size_t*, size_t, uint8_t* const*, size_t*, hipcompStatus_t*);
 
 template <int S>
-CompressKernel compress_kernel_of(uint32_t cb, uint32_t& lds)
-{
-  switch (cb) {
-  case 8192: lds = kWavesPerBlock * wave_lds_bytes<S, 8192>(); return cascaded_compress_kernel<S, 8192>;
-  case 16384: lds = kWavesPerBlock * wave_lds_bytes<S, 16384>(); return cascaded_compress_kernel<S, 16384>;
-  default: lds = kWavesPerBlock * wave_lds_bytes<S, 4096>(); return cascaded_compress_kernel<S, 4096>;
-  }
-}
-
-template <int S, int CB>
 hipError_t launch_decompress(
     const uint8_t* const* comp_ptrs, const size_t* comp_bytes, const size_t* out_caps, size_t batch,
     uint8_t* const* out_ptrs, size_t* actual_bytes, hipcompStatus_t* statuses, hipStream_t stream)
 {
-  DecompressKernel k = cascaded_decompress_kernel<S, CB>;
-  constexpr uint32_t lds = dec_lds_bytes<S, CB>();
-  if (lds > 64 * 1024) { // has to be asked for (idempotent, cheap)
-    const hipError_t e
-        = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess)
-      return e;
-  }
+  DecompressKernel k = cascaded_decompress_kernel<S>;
+  constexpr uint32_t lds = dec_lds_bytes<S>();
+  static_assert(lds <= 64 * 1024, "fits the default dynamic LDS limit: no attribute to raise");
   // as many one-wave workgroups as the chip holds with this much LDS each (handed out in 1280-byte granules)
   uint32_t per_cu = (160u * 1024u) / ((lds + 1279u) / 1280u * 1280u);
   if (per_cu > 32)
@@ -927,47 +1514,46 @@ hipError_t launch_decompress(
   const size_t resident = (size_t)num_cus_of_current_device() * per_cu;
   k<<<dim3((unsigned)(batch < resident ? batch : resident)), dim3(kWave), lds, stream>>>(
       comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);
-  return hipSuccess;
+  return hipGetLastError();
 }
 
 } // namespace
 
-// chunk_bytes: 4096, 8192 or 16384 (the caller maps every other value to 4096)
 void cascaded_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, size_t batch, int type_tag,
-    int elem_size, int num_rles, int num_deltas, int use_bp, uint32_t chunk_bytes, hipStream_t stream)
+    int elem_size, int num_rles, int num_deltas, int use_bp, hipStream_t stream)
 {
   const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock));
   const dim3 block(kWave * kWavesPerBlock);
-  uint32_t lds = 0;
-  CompressKernel k = elem_size == 1   ? compress_kernel_of<1>(chunk_bytes, lds)
-                     : elem_size == 2 ? compress_kernel_of<2>(chunk_bytes, lds)
-                     : elem_size == 4 ? compress_kernel_of<4>(chunk_bytes, lds)
-                                      : compress_kernel_of<8>(chunk_bytes, lds);
+  CompressKernel k = elem_size == 1   ? cascaded_compress_kernel<1>
+                     : elem_size == 2 ? cascaded_compress_kernel<2>
+                     : elem_size == 4 ? cascaded_compress_kernel<4>
+                                      : cascaded_compress_kernel<8>;
+  const uint32_t lds = kWavesPerBlock
+                       * (elem_size == 1   ? wave_lds_bytes<1>()
+                          : elem_size == 2 ? wave_lds_bytes<2>()
+                          : elem_size == 4 ? wave_lds_bytes<4>()
+                                           : wave_lds_bytes<8>());
   k<<<grid, block, lds, stream>>>(in_ptrs, in_bytes, out_ptrs, out_bytes, batch, type_tag, num_rles, num_deltas, use_bp);
 }
 
-// One launch per element width and sub-chunk size (the reference: one per
-// width); a launch leaves the partitions of the others alone.  The common
-// ones first.
+// One launch per element width, as the reference (CascadedBatch.hip:387-429) -- but a launch
+// leaves the partitions of the other widths alone instead of decoding everything with the
+// width of partition 0.  The common width first.
 hipError_t cascaded_launch_decompress(
     const uint8_t* const* comp_ptrs, const size_t* comp_bytes,
     const size_t* out_caps, size_t batch, uint8_t* const* out_ptrs,
     size_t* actual_bytes, hipcompStatus_t* statuses, hipStream_t stream)
 {
-  // (every launch is set up before the first one runs anything the caller could see half-done:
-  // the LDS limits are raised first, in the order of the launches)
-#define HC_DEC(S, CB)                                                                                              \
-  {                                                                                                                \
-    const hipError_t e = launch_decompress<S, CB>(comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, \
-                                                  statuses, stream);                                               \
-    if (e != hipSuccess)                                                                                           \
-      return e;                                                                                                    \
+#define HC_DEC(S)                                                                                              \
+  {                                                                                                            \
+    const hipError_t e = launch_decompress<S>(comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, \
+                                              statuses, stream);                                               \
+    if (e != hipSuccess)                                                                                       \
+      return e;                                                                                                \
   }
-  HC_DEC(4, 4096) HC_DEC(8, 4096) HC_DEC(2, 4096) HC_DEC(1, 4096)
-  HC_DEC(4, 8192) HC_DEC(8, 8192) HC_DEC(2, 8192) HC_DEC(1, 8192)
-  HC_DEC(4, 16384) HC_DEC(8, 16384) HC_DEC(2, 16384) HC_DEC(1, 16384)
+  HC_DEC(4) HC_DEC(8) HC_DEC(2) HC_DEC(1)
 #undef HC_DEC
   return hipSuccess;
 }

@@ -12,7 +12,7 @@ namespace hcamd {
 void cascaded_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, size_t batch, int type_tag,
-    int elem_size, int num_rles, int num_deltas, int use_bp, uint32_t chunk_bytes, hipStream_t stream);
+    int elem_size, int num_rles, int num_deltas, int use_bp, hipStream_t stream);
 
 // an error: a launch could not be set up (nothing was decoded by it; the caller fails the call)
 hipError_t cascaded_launch_decompress(

@@ -224,10 +224,14 @@ Lz4CompressShape lz4_compress_shape_mix(uint32_t ht_size, size_t batch)
   return sh;
 }
 
+// The library that ships reads nothing from the environment: every chunk goes where the routing
+// kernel sends it.  The knobs below exist in the measurement / test build only
+// (`make VARIANT=knobs EXTRA=-DHC_MEASUREMENT_KNOBS` -> lib/libhipcomp_knobs.so: the same device code,
+// tests/test_build_guards_cpu.py compares the code objects), where they are read at every call so that
+// the tests can switch shapes inside one process.
 Lz4Mode lz4_mode_from_environment()
 {
-  // read at every call (a getenv is nanoseconds beside a launch): the tests
-  // switch shapes inside one process
+#ifdef HC_MEASUREMENT_KNOBS
   const char* e = std::getenv("HIPCOMP_LZ4_SHAPE");
   if (e && std::strcmp(e, "mix") == 0)
     return Lz4Mode::Mix;
@@ -237,6 +241,7 @@ Lz4Mode lz4_mode_from_environment()
     return Lz4Mode::FarSparse;
   if (e && std::strcmp(e, "farw") == 0)
     return Lz4Mode::FarWide;
+#endif
   return Lz4Mode::Auto;
 }
 
@@ -252,10 +257,11 @@ struct FarGeometry
   uint32_t waves() const { return near + far; }
 };
 
-// Measurement knob HIPCOMP_LZ4_GEOMETRY="near,far,slots": that geometry for every
+// Measurement knob HIPCOMP_LZ4_GEOMETRY="near,far,slots" (knobs build only): that geometry for every
 // far-type launch, as many workgroups as fit a CU.
 bool geometry_from_environment(uint32_t& near, uint32_t& far, uint32_t& slots)
 {
+#ifdef HC_MEASUREMENT_KNOBS
   const char* e = std::getenv("HIPCOMP_LZ4_GEOMETRY");
   unsigned a = 0, b = 0, c = 0;
   if (e && std::sscanf(e, "%u,%u,%u", &a, &b, &c) == 3 && a + b >= 1 && a + b <= (unsigned)kFarMaxWavesPerGroup
@@ -265,17 +271,24 @@ bool geometry_from_environment(uint32_t& near, uint32_t& far, uint32_t& slots)
     slots = c;
     return true;
   }
+#else
+  (void)near;
+  (void)far;
+  (void)slots;
+#endif
   return false;
 }
 
-// lanes a trip of the device-table waves' lean form looks up (HIPCOMP_LZ4_SPAN: measurement knob)
+// lanes a trip of the device-table waves' lean form looks up (HIPCOMP_LZ4_SPAN: measurement knob, knobs build only)
 uint32_t far_span(uint32_t cls)
 {
+#ifdef HC_MEASUREMENT_KNOBS
   if (const char* e = std::getenv("HIPCOMP_LZ4_SPAN")) {
     const int v = std::atoi(e);
     if (v >= 8 && v <= 64)
       return (uint32_t)v;
   }
+#endif
   return cls == kClassDense ? (uint32_t)kFarSpanFull : (uint32_t)kFarSpan;
 }
 

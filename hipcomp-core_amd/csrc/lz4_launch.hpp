@@ -33,8 +33,9 @@ struct Lz4CompressShape
 Lz4CompressShape lz4_compress_shape_mix(uint32_t ht_size, size_t batch);
 
 enum class Lz4Mode { Auto, Mix, Far, FarSparse, FarWide };
-// HIPCOMP_LZ4_SHAPE = auto | mix | far | fars | farw (read at every call; default auto).  A
-// measurement / test knob: the compressed bytes do not depend on it.  auto: a routing kernel
+// Auto in the library that ships.  The measurement / test build (-DHC_MEASUREMENT_KNOBS,
+// lib/libhipcomp_knobs.so) reads HIPCOMP_LZ4_SHAPE = auto | mix | far | fars | farw at every call;
+// the compressed bytes do not depend on it.  auto: a routing kernel
 // puts every chunk on the list of the shape its data calls for; the others run every chunk
 // through one shape (far / fars: the lean form with the launch geometry for dense / sparse data).
 Lz4Mode lz4_mode_from_environment();

@@ -72,6 +72,11 @@ constexpr uint32_t kStraightMargin = 64 + 8 + 64 + 8;
 #define HC_SNAPPY_SPAN 52 // (measurement builds: 16..52; 32: 71.2, 40: 77.4, 48: 82.7, 52: 84.0 GB/s on text)
 #endif
 constexpr int kSpan = HC_SNAPPY_SPAN;
+// pick() below takes the first event at or above `start` with `start` clamped to lane 63: with an event AT lane
+// 63 and an element that ends beyond lane 63 it would take that same event again and again (an endless loop,
+// met in round 3 with a 64-lane span).  Lanes from kSpan on never report an event, so the span has to stop short
+// of lane 63.
+static_assert(kSpan >= 8 && kSpan < 64, "the straight path's pick() relies on bit 63 of `events` never being set");
 constexpr uint32_t kStraightReach = 64; // (two registers of words: all 64 lanes of the next window are there)
 
 __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
       int t;
       uint64_t touched;
       auto pick = [&]() -> uint32_t {
-        t = first_set_or_minus_one(events & (~0ull << min(start, 63u))); // (bit 63 of events is never set)
+        t = first_set_or_minus_one(events & (~0ull << min(start, 63u))); // (bit 63 of events is never set: kSpan < 64, static_assert above)
         if (t < 0)
           return 0u;
         const uint64_t range = (2ull << t) - (1ull << start); // lanes start..t

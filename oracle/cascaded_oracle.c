@@ -43,17 +43,8 @@
 #include <stdint.h>
 #include <string.h>
 
-#define CHUNK_BYTES 4096      /* the reference's (hard-wired) sub-chunk, CascadedKernels.hiph:88 */
-#define MAX_CHUNK_BYTES 16384 /* this library honours opts.chunk_size 8192 and 16384 as well */
+#define CHUNK_BYTES 4096 /* the reference's (hard-wired) sub-chunk, CascadedKernels.hiph:88; opts.chunk_size is ignored */
 #define PART_META 8
-
-/* Sub-chunk sizes other than the reference's are an extension of the format:
- * the high nibble of header byte 2 (use_bp, 0 or 1 in the reference) says
- * which -- 0: 4096 (every reference stream), 1: 8192, 2: 16384. */
-static int chunk_code_of(size_t chunk_bytes)
-{
-  return chunk_bytes == 8192 ? 1 : chunk_bytes == 16384 ? 2 : 0;
-}
 
 static size_t ru(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
@@ -180,13 +171,12 @@ static size_t write_array(
  * s its size in bytes.  out/mask must hold oracle_cascaded_max_compressed_size
  * (in_bytes) bytes (and are fully initialised: untouched bytes get mask 0).
  */
-int oracle_cascaded_compress_cb(
-    const uint8_t* in, size_t in_bytes, int type, int s, int R, int D, int bp, size_t chunk_bytes,
+int oracle_cascaded_compress(
+    const uint8_t* in, size_t in_bytes, int type, int s, int R, int D, int bp,
     uint8_t* out, uint8_t* mask, size_t* out_bytes)
 {
-  static __thread uint64_t a[MAX_CHUNK_BYTES], b[MAX_CHUNK_BYTES], cnt[MAX_CHUNK_BYTES]; /* per thread: timed from a thread pool */
-  const int code = chunk_code_of(chunk_bytes);
-  const size_t cb = code == 1 ? 8192 : code == 2 ? 16384 : CHUNK_BYTES; /* anything else: the reference's */
+  static __thread uint64_t a[CHUNK_BYTES], b[CHUNK_BYTES], cnt[CHUNK_BYTES]; /* per thread: timed from a thread pool */
+  const size_t cb = CHUNK_BYTES;
   const size_t cap = oracle_cascaded_max_compressed_size(in_bytes);
   memset(out, 0, cap);
   memset(mask, 0, cap);
@@ -270,7 +260,7 @@ int oracle_cascaded_compress_cb(
 
   uint8_t hdr[8];
   if (use) {
-    hdr[0] = (uint8_t)R; hdr[1] = (uint8_t)D; hdr[2] = (uint8_t)((bp ? 1 : 0) | (code << 4));
+    hdr[0] = (uint8_t)R; hdr[1] = (uint8_t)D; hdr[2] = (uint8_t)(bp ? 1 : 0);
     *out_bytes = cur;
   } else {                                               /* :1019-1053 */
     memset(out, 0, cap);
@@ -285,13 +275,6 @@ int oracle_cascaded_compress_cb(
   memcpy(hdr + 4, &ub, 4);
   put(&k, 0, hdr, 8, 1);
   return 0;
-}
-
-int oracle_cascaded_compress(
-    const uint8_t* in, size_t in_bytes, int type, int s, int R, int D, int bp,
-    uint8_t* out, uint8_t* mask, size_t* out_bytes)
-{
-  return oracle_cascaded_compress_cb(in, in_bytes, type, s, R, D, bp, CHUNK_BYTES, out, mask, out_bytes);
 }
 
 /* get_decompress_size_kernel, CascadedBatch.hip:262-281 */
@@ -350,15 +333,14 @@ static long read_array(
 int oracle_cascaded_decompress(
     const uint8_t* comp, size_t comp_bytes, uint8_t* out, size_t cap, size_t* actual)
 {
-  static __thread uint64_t a[MAX_CHUNK_BYTES], b[MAX_CHUNK_BYTES], cnt[MAX_CHUNK_BYTES]; /* per thread: timed from a thread pool */
+  static __thread uint64_t a[CHUNK_BYTES], b[CHUNK_BYTES], cnt[CHUNK_BYTES]; /* per thread: timed from a thread pool */
   static const int sizes[8] = {1, 1, 2, 2, 4, 4, 8, 8};
   *actual = 0;
   if (comp_bytes < PART_META)
     return 12;
   const int R = comp[0], D = comp[1], bp = comp[2] & 0x0F, type = comp[3];
-  const int code = comp[2] >> 4;                         /* sub-chunk size (see chunk_code_of) */
-  if (code > 2) return 12;
-  const size_t cb = code == 1 ? 8192 : code == 2 ? 16384 : CHUNK_BYTES;
+  if (comp[2] >> 4) return 12;   /* byte 2 is use_bp, 0 or 1 (rounds 2-3 marked larger sub-chunks, an extension that is gone, here) */
+  const size_t cb = CHUNK_BYTES;
   if (type > 7) return 12;
   const int s = sizes[type];
   uint32_t ub;

@@ -58,9 +58,6 @@ def lib():
         L.oracle_cascaded_compress.argtypes = [c_char_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                c_void_p, POINTER(c_size_t)]
         L.oracle_cascaded_compress.restype = c_int
-        L.oracle_cascaded_compress_cb.argtypes = [c_char_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_size_t, c_void_p,
-                                                  c_void_p, POINTER(c_size_t)]
-        L.oracle_cascaded_compress_cb.restype = c_int
         L.oracle_cascaded_decompressed_size.argtypes = [c_char_p, c_size_t]
         L.oracle_cascaded_decompressed_size.restype = c_size_t
         L.oracle_cascaded_decompress.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t)]
@@ -146,18 +143,16 @@ def cascaded_max_compressed_size(n: int) -> int:
     return lib().oracle_cascaded_max_compressed_size(n)
 
 
-def cascaded_compress(data: bytes, type_tag: int, num_rles: int, num_deltas: int, use_bp: int, chunk_bytes: int = 4096):
+def cascaded_compress(data: bytes, type_tag: int, num_rles: int, num_deltas: int, use_bp: int):
     """-> (compressed bytes, mask bytes).  mask 0xFF = byte defined by the
     format, 0x00 = don't-care byte (stale LDS / unwritten gap in the reference).
-    chunk_bytes: the sub-chunk size (4096 = the reference's; 8192 / 16384 = this
-    library's extension, anything else is taken as 4096 like the reference does)."""
+    (Sub-chunks are the reference's 4096 bytes: it ignores opts.chunk_size.)"""
     cap = cascaded_max_compressed_size(len(data))
     out = ctypes.create_string_buffer(cap)
     mask = ctypes.create_string_buffer(cap)
     n = c_size_t(0)
-    rc = lib().oracle_cascaded_compress_cb(data, len(data), type_tag, CASCADED_TYPE_SIZE[type_tag], num_rles, num_deltas,
-                                           use_bp, chunk_bytes, ctypes.cast(out, c_void_p), ctypes.cast(mask, c_void_p),
-                                           ctypes.byref(n))
+    rc = lib().oracle_cascaded_compress(data, len(data), type_tag, CASCADED_TYPE_SIZE[type_tag], num_rles, num_deltas,
+                                        use_bp, ctypes.cast(out, c_void_p), ctypes.cast(mask, c_void_p), ctypes.byref(n))
     if rc != 0:
         raise ValueError("oracle_cascaded_compress: unsupported options")
     return out.raw[: n.value], mask.raw[: n.value]

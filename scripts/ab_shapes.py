@@ -26,7 +26,7 @@ LIBS = {}
 def lib_of(cfg):
     variant = cfg.split("+")[0].partition("@")[2]
     if variant not in LIBS:
-        LIBS[variant] = hc.HipcompLibrary(os.path.join(ROOT, "hipcomp-core_amd", "lib", f"libhipcomp_{variant}.so")) if variant else hc.default_library()
+        LIBS[variant] = hc.HipcompLibrary(os.path.join(ROOT, "hipcomp-core_amd", "lib", f"libhipcomp_{variant}.so")) if variant else hc.knobs_library()  # (the knobs are read by the knobs build only)
     return LIBS[variant]
 
 

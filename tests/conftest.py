@@ -38,15 +38,27 @@ def reflib(hc):
 LZ4_SHAPES = ("auto", "mix", "far", "fars", "farw")
 
 
+def force_lz4_shape(hc, monkeypatch, shape):
+    """Makes hc.batch.Codec(...) without a `lib` use the library that `shape` needs: the product
+    (lib/libhipcomp.so: it reads nothing from the environment, every chunk goes where the routing
+    kernel sends it) for "auto", the knobs build (lib/libhipcomp_knobs.so: the same sources and the
+    same device code -- tests/test_build_guards_cpu.py -- with HIPCOMP_LZ4_SHAPE read at every call)
+    for a forced shape."""
+    if shape == "auto":
+        monkeypatch.delenv("HIPCOMP_LZ4_SHAPE", raising=False)
+        return
+    monkeypatch.setenv("HIPCOMP_LZ4_SHAPE", shape)
+    monkeypatch.setattr(hc.batch, "default_library", hc.knobs_library)
+
+
 @pytest.fixture(params=LZ4_SHAPES)
-def lz4_shape(request, monkeypatch):
-    """Every launch shape of the LZ4 encoder in turn (HIPCOMP_LZ4_SHAPE is read at
-    every call): "auto" lets the routing kernel send every chunk to the shape
-    its data calls for, the others force one for all chunks -- also on data it
-    would never be picked for (the far shapes on chunks without a match, the
-    LDS shape and the wide form on text).  The compressed bytes must not depend
-    on it."""
-    monkeypatch.setenv("HIPCOMP_LZ4_SHAPE", request.param)
+def lz4_shape(request, monkeypatch, hc):
+    """Every launch shape of the LZ4 encoder in turn: "auto" (the product library) lets the routing
+    kernel send every chunk to the shape its data calls for, the others (the knobs build, see
+    force_lz4_shape) force one for all chunks -- also on data it would never be picked for (the far
+    shapes on chunks without a match, the LDS shape and the wide form on text).  The compressed
+    bytes must not depend on it."""
+    force_lz4_shape(hc, monkeypatch, request.param)
     return request.param
 
 

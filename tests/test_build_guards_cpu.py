@@ -125,3 +125,68 @@ def test_hazard_guard_catches_what_it_is_there_for(tmp_path):
     # the same pair wholly in compiler-scheduled code is not ours: reported as calibration, not as a failure
     r = _haz(_snippet(tmp_path, cases["H1"].replace("\t;;#ASMSTART\n", "").replace("\t;;#ASMEND\n", "")))
     assert r.returncode == 0 and "calibration" in r.stderr
+
+
+def test_hazard_guard_follows_branches_inside_asm_statements(tmp_path):
+    """The loops inside asm statements (`1: ... s_cbranch_scc1 1b`): the last instructions of the body are
+    predecessors of the first ones, and a forward branch that is taken skips the instructions between."""
+    loop_h10 = ("\t;;#ASMSTART\n1:\n\tv_cndmask_b32_e64 v0, v1, v2, s[4:5]\n\ts_add_u32 s6, s6, 1\n\ts_cmp_lt_u32 s6, 8\n"
+                "\tv_cmp_ne_u32_e64 s[4:5], s6, v2\n\ts_cbranch_scc1 1b\n\t;;#ASMEND\n")
+    r = _haz(_snippet(tmp_path, loop_h10))
+    assert r.returncode == 1 and "H10" in r.stderr and "across the branch" in r.stderr, r.stderr
+    # the compare one instruction earlier in the body: two wait states (the s_cmp, the branch) -- fine
+    r = _haz(_snippet(tmp_path, loop_h10.replace("\ts_cmp_lt_u32 s6, 8\n\tv_cmp_ne_u32_e64 s[4:5], s6, v2\n",
+                                                 "\tv_cmp_ne_u32_e64 s[4:5], s6, v2\n\ts_cmp_lt_u32 s6, 8\n")))
+    assert r.returncode == 0, r.stderr
+    # loop-carried H9's sibling with a lane select (H1, four states): the walks' shape with the select made by a VALU instruction
+    loop_h1 = ("\t;;#ASMSTART\n1:\n\tv_readlane_b32 s7, v9, s4\n\ts_cmp_lt_i32 s7, 0\n\tv_readfirstlane_b32 s4, v3\n"
+               "\ts_cbranch_scc1 1b\n\t;;#ASMEND\n")
+    r = _haz(_snippet(tmp_path, loop_h1))
+    assert r.returncode == 1 and "H1 " in r.stderr, r.stderr
+    # a DPP read at the loop head of a register the loop tail's VALU instruction wrote (H3, two states)
+    loop_h3 = ("\t;;#ASMSTART\n1:\n\tv_mov_b32_dpp v4, v3 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_add_u32 s6, s6, 1\n"
+               "\ts_cmp_lt_u32 s6, 8\n\tv_add_u32_e32 v3, v3, v4\n\ts_cbranch_scc1 1b\n\t;;#ASMEND\n")
+    r = _haz(_snippet(tmp_path, loop_h3))
+    assert r.returncode == 1 and "H3" in r.stderr, r.stderr
+    # forward: the fall-through path has its s_nop, the taken path jumps past it
+    fwd = ("\t;;#ASMSTART\n\tv_readfirstlane_b32 s4, v1\n\ts_cbranch_scc0 2f\n\ts_nop 3\n2:\n\tv_readlane_b32 s5, v2, s4\n\t;;#ASMEND\n")
+    r = _haz(_snippet(tmp_path, fwd))
+    assert r.returncode == 1 and "H1 " in r.stderr and "across the branch" in r.stderr, r.stderr
+    r = _haz(_snippet(tmp_path, fwd.replace("\ts_cbranch_scc0 2f\n\ts_nop 3\n", "\ts_nop 3\n\ts_cbranch_scc0 2f\n")))
+    assert r.returncode == 0, r.stderr
+    # a compiler label as the target (.LBB...), producer in compiler code, consumer in an asm statement
+    r = _haz(_snippet(tmp_path, ".LBB0_1:\n\t;;#ASMSTART\n\tv_readlane_b32 s7, v9, 0\n\t;;#ASMEND\n\tv_or_b32_e32 v9, v1, v2\n\ts_cbranch_vccnz .LBB0_1\n"))
+    assert r.returncode == 0, r.stderr   # (the branch is the one state H9 asks for)
+    r = _haz(_snippet(tmp_path, ".LBB0_1:\n\t;;#ASMSTART\n\tv_cndmask_b32_e64 v0, v1, v2, s[4:5]\n\t;;#ASMEND\n\tv_cmp_ne_u32_e64 s[4:5], s6, v2\n\ts_cbranch_vccnz .LBB0_1\n"))
+    assert r.returncode == 1 and "H10" in r.stderr, r.stderr
+
+
+# ---- the library that ships has no knobs; the knobs build is the same device code ------------------
+def test_product_library_reads_nothing_from_the_environment_and_knobs_build_is_the_same_device_code():
+    """lib/libhipcomp.so: no HIPCOMP_* string, no getenv import.  lib/libhipcomp_knobs.so (csrc/Makefile
+    VARIANT=knobs: -DHC_MEASUREMENT_KNOBS, read by the tests that force a launch shape): the device
+    assembly of every kernel object is the product's, line for line (the macro touches host code only;
+    hipcc names a compilation unit after a hash of its command line: __hip_cuid_<hash>)."""
+    import glob
+    lib = os.path.join(ROOT, "hipcomp-core_amd", "lib", "libhipcomp.so")
+    knobs = os.path.join(ROOT, "hipcomp-core_amd", "lib", "libhipcomp_knobs.so")
+    assert os.path.exists(lib) and os.path.exists(knobs), "run build()"
+    blob = open(lib, "rb").read()
+    assert b"HIPCOMP_LZ4" not in blob and b"HIPCOMP_CASCADED" not in blob
+    und = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
+    assert "getenv" not in und, und
+    assert b"HIPCOMP_LZ4_SHAPE" in open(knobs, "rb").read()
+
+    def device_code(path):
+        out = []
+        for line in open(path):
+            line = line.split(";", 1)[0].rstrip()
+            if line:
+                out.append(re.sub(r"__hip_cuid_[0-9a-f]+", "__hip_cuid_X", line))
+        return out
+    files = sorted(glob.glob(os.path.join(CSRC, "build", "*.gfx950.s")))
+    assert len(files) >= 5
+    for f in files:
+        k = os.path.join(CSRC, "build_knobs", os.path.basename(f))
+        assert os.path.exists(k), k
+        assert device_code(f) == device_code(k), os.path.basename(f)

@@ -158,60 +158,26 @@ def test_large_partitions(hc, oracle, reflib, cuda):
     compare_with_reference(reflib, "Cascaded large partitions", check)
 
 
-def test_chunk_size_is_ignored_by_default_as_in_the_reference(hc, oracle, reflib, cuda, monkeypatch):
+def test_chunk_size_is_ignored_as_in_the_reference(hc, oracle, reflib, cuda):
     """The reference ignores opts.chunk_size (cascaded.h:93-100) and always writes 4096-byte
-    sub-chunks; so does the product unless the extension is switched on: a caller that passes
-    8192 gets the reference's bytes."""
-    monkeypatch.delenv("HIPCOMP_CASCADED_CHUNK_SIZE", raising=False)
+    sub-chunks; so does the product: whatever a caller passes, it gets the reference's bytes.  And a
+    stream whose header claims something else in the high nibble of byte 2 (the extension of
+    rounds 2-3, removed) is refused like any undecodable header."""
     data = _sorted_column(2, 16384).tobytes()
     src = hc.batch.from_host_chunks([data], "cuda:0")
     want, mask = oracle.cascaded_compress(data, 5, 2, 1, 1)
-    for cb in (4096, 8192, 16384, 512):
+    for cb in (4096, 8192, 16384, 512, 0):
         assert hc.batch.Codec("Cascaded", hc.CascadedOpts(cb, 5, 2, 1, 1)).compress(src).to_host_chunks()[0] == want
+    bad = [want[:2] + bytes([want[2] | (code << 4)]) + want[3:] for code in (1, 2, 7)]
+    comp = hc.batch.from_host_chunks(bad + [want], "cuda:0")
+    dec, actual, statuses = hc.batch.Codec("Cascaded").decompress(comp, 65536)
+    assert statuses.cpu().tolist() == [12, 12, 12, 0] and actual.cpu().tolist() == [0, 0, 0, len(data)]
+    assert dec.chunk_bytes(3, len(data)) == data
+    for b in bad:
+        assert oracle.cascaded_decompress(b, len(data)) == (12, b"")
 
     def check(reflib):
         for cb in (4096, 8192, 16384):
             got = hc.batch.Codec("Cascaded", hc.CascadedOpts(cb, 5, 2, 1, 1), lib=reflib).compress(src).to_host_chunks()[0]
             assert oracle.masked_equal(got, want, mask)
     compare_with_reference(reflib, "chunk_size ignored", check)
-
-
-@pytest.mark.parametrize("cb", [8192, 16384])
-def test_chunk_size_option_is_honoured(hc, oracle, cuda, monkeypatch, cb):
-    """The extension (HIPCOMP_CASCADED_CHUNK_SIZE=honour): chunk_size 8192 / 16384,
-    kernel == oracle byte for byte, round trips, and partitions of all three sub-chunk sizes and
-    several types decode side by side in one batch (the decoder needs no switch)."""
-    import torch
-    monkeypatch.setenv("HIPCOMP_CASCADED_CHUNK_SIZE", "honour")
-    for R, D, bp in ((2, 1, 1), (1, 0, 0), (0, 2, 1)):
-        mixed, expect = [], []
-        for t in range(8):
-            chunks = _inputs(t, oracle)
-            src = hc.batch.from_host_chunks(chunks, "cuda:0")
-            codec = hc.batch.Codec("Cascaded", hc.CascadedOpts(cb, t, R, D, bp))
-            mine = codec.compress(src)
-            torch.cuda.synchronize()
-            got = mine.to_host_chunks()
-            s = oracle.CASCADED_TYPE_SIZE[t]
-            for i, c in enumerate(chunks):
-                want, _ = oracle.cascaded_compress(c, t, R, D, bp, cb)
-                assert got[i] == want, f"type {t} opts {(R, D, bp)} chunk_size {cb} input {i}: kernel != oracle"
-            dec, actual, statuses = codec.decompress(mine, 65536 * 2)
-            for i, c in enumerate(chunks):
-                if len(c):
-                    e = c[: len(c) // s * s]
-                    assert statuses[i].item() == 0 and dec.chunk_bytes(i, int(actual[i].item())) == e
-            mixed += [got[0], oracle.cascaded_compress(chunks[1], t, R, D, bp)[0],
-                      oracle.cascaded_compress(chunks[0], t, R, D, bp, 24576 - cb)[0]]
-            expect += [chunks[0][: len(chunks[0]) // s * s], chunks[1][: len(chunks[1]) // s * s],
-                       chunks[0][: len(chunks[0]) // s * s]]
-        comp = hc.batch.from_host_chunks(mixed, "cuda:0")
-        dec, actual, statuses = hc.batch.Codec("Cascaded").decompress(comp, 65536 * 2)
-        assert statuses.cpu().tolist() == [0] * len(mixed)
-        for i, e in enumerate(expect):
-            assert dec.chunk_bytes(i, int(actual[i].item())) == e
-    # any other chunk_size means the reference's 4096
-    src = hc.batch.from_host_chunks([_sorted_column(1, 16384).tobytes()], "cuda:0")
-    a = hc.batch.Codec("Cascaded", hc.CascadedOpts(4096, 5, 2, 1, 1)).compress(src).to_host_chunks()
-    b = hc.batch.Codec("Cascaded", hc.CascadedOpts(12345, 5, 2, 1, 1)).compress(src).to_host_chunks()
-    assert a == b

@@ -10,6 +10,8 @@ import zlib
 
 import pytest
 
+from conftest import force_lz4_shape
+
 import datagen
 
 pytestmark = pytest.mark.gpu
@@ -36,7 +38,7 @@ def _check(rec, got, what):
 @pytest.mark.parametrize("shape", ["auto", "mix", "far", "fars", "farw"])
 def test_lz4_kernels_reproduce_the_golden_vectors(hc, cuda, monkeypatch, shape):
     import torch
-    monkeypatch.setenv("HIPCOMP_LZ4_SHAPE", shape)
+    force_lz4_shape(hc, monkeypatch, shape)
     with open(os.path.join(HERE, "golden", "lz4_reference.json")) as f:
         recs = json.load(f)["lz4"]
     inputs = _inputs()

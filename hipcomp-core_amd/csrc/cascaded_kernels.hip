@@ -34,6 +34,7 @@
 #include "lz4_launch.hpp" // num_cus_of_current_device
 #include "wave_utils.hpp"
 
+#include <atomic>
 #include <type_traits>
 
 namespace hcamd {
@@ -98,8 +99,8 @@ constexpr uint32_t kStageWords = kStagePerLane * kWave;
 template <int S>
 __host__ __device__ constexpr uint32_t dec_lds_bytes()
 {
-  // two element buffers + run markers + staged sub-chunk
-  return 2 * dec_buf_bytes() + (CB / S) * 2 + kStageWords * 4;
+  // two element buffers + run markers + staged sub-chunk; 4-byte elements (the fast path): padded buffers
+  return S == 4 ? 1024 + (1024 + 32) * 4 + 2048 + 16 : 2 * dec_buf_bytes() + (CB / S) * 2 + kStageWords * 4;
 }
 
 // E elements p[0 .. E) of an LDS array (p 16-byte aligned) into registers
@@ -1118,14 +1119,244 @@ __device__ __forceinline__ UT prefix_store_shifted(
   return (UT)(carry + total);
 }
 
+// ---------------------------------------------------------------------------
+// 4-byte elements: the decoder's fast path (round 4), the mirror of the encoder's (rle16 /
+// write_array4).  Element buffers in the padded layout (a dword behind every 32 elements: a lane's
+// block of 32 or 16 consecutive elements is conflict-free dword by dword); a bit-packed array comes
+// out of its words 32 elements per lane with compile-time shifts (one v_bfe / v_alignbit per
+// element); the run lengths never touch LDS: their prefix sum is 32 additions inside the lane plus
+// one wave scan, and every run drops its marker at its start position itself.
+// What bounds this decoder is how many waves a CU holds (PMC: no unit half busy, the waves wait on
+// their own LDS round trips; rounds 2-3 measured throughput proportional to the waves: 10 / 12 / 14 per
+// CU = 713 / 844 / 960 GB/s), and LDS is what limits them.  So ONE element buffer: a sub-chunk of 4-byte
+// elements is a single round of 64 lanes x 16 elements, all of whose reads come before its stores (LDS
+// operations of a wave execute in order), so every pass -- an RLE expansion, a delta layer, the
+// unpacking of an array whose words had to be copied in from HBM first -- works in place.
+// LDS of a wave: [stage 1 KiB][element buffer, padded][markers 2 KiB + one entry] = 7 312 bytes, 6
+// allocation granules: 21 waves per CU (rounds 1-3: two buffers, 14).  The one entry behind the
+// markers: the runs of a lane behind the last run of the array (their bits read as 0) put their
+// markers at `total`, behind the output, where nothing looks -- entry 1024 when the sub-chunk is full.
+// ---------------------------------------------------------------------------
+#define HC_LDS __attribute__((address_space(3)))
+constexpr uint32_t kDec4Stage = 0, kDec4X = 1024, kDec4Marks = 1024 + kX4Bytes;
+constexpr uint32_t kDec4Bytes = kDec4Marks + 2048 + 16;
+
+// element k (0 .. 31) of BW bits out of the BW words w (LSB first, reference block_bitunpack :563-618)
+template <int BW>
+__device__ __forceinline__ uint32_t unpacked(const uint32_t (&w)[BW == 0 ? 1 : BW], int k)
+{
+  if (BW == 0)
+    return 0u;
+  const int p = k * BW, word = p >> 5, sh = p & 31;
+  uint32_t x = w[word % (BW == 0 ? 1 : BW)] >> sh;
+  if (sh + BW > 32)
+    x |= w[(word + 1) % (BW == 0 ? 1 : BW)] << (32 - sh);
+  return BW >= 32 ? x : x & ((1u << (BW & 31)) - 1u);
+}
+
+// What an array header says (reference block_read :702-737 + block_bitunpack :563-618, bounds as in
+// unpack_array above): the element count (-1: the array leaves the sub-chunk buffer or is
+// malformed), and for n > 0 the bit width, the frame of reference and where the words begin.
+template <int ES, typename WordPtr>
+__device__ __forceinline__ int open_array4(
+    WordPtr src, uint32_t nbytes, int bp, uint32_t max_elems, uint32_t& bw, uint32_t& fr, WordPtr& data, uint32_t& words)
+{
+  if (!bp) {
+    const uint32_t n = nbytes / ES;
+    if (n > max_elems)
+      return -1;
+    bw = 8 * ES;
+    fr = 0;
+    data = src;
+    words = (n * ES + 3) / 4;
+    return (int)n;
+  }
+  if (nbytes < 8)
+    return -1;
+  fr = uniform((uint32_t)src[0]);
+  const uint32_t word = uniform((uint32_t)src[1]);
+  bw = word >> 16;
+  const uint32_t n = word & 0xFFFFu;
+  if (n == 0)
+    return 0;
+  if (n > max_elems || bw > 8 * ES)
+    return -1;
+  words = (n * bw + 31) / 32;
+  if (8 + 4 * words > ru(nbytes, 4))
+    return -1;
+  data = src + 2;
+  return (int)n;
+}
+
+// my BW words of an array of `words` words: [lane BW, lane BW + BW), the ones behind the array read
+// as its last word (in bounds); then the bits behind element n are cleared
+template <int BW, typename WordPtr>
+__device__ __forceinline__ void load_words(
+    WordPtr data, uint32_t words, uint32_t n, uint32_t (&w)[BW == 0 ? 1 : BW], int lane)
+{
+  if (BW == 0) {
+    w[0] = 0;
+    return;
+  }
+  const uint32_t w0 = (uint32_t)lane * BW;
+#pragma unroll
+  for (int j = 0; j < BW; ++j)
+    w[j] = data[min(w0 + (uint32_t)j, words - 1u)];
+  // bits of mine that belong to elements: n BW - 32 w0, clamped to [0, 32 BW]
+  const int32_t left = (int32_t)(n * BW) - (int32_t)(32u * w0);
+  if (left < 32 * BW) { // (the lane the array ends in, and the lanes behind it)
+#pragma unroll
+    for (int j = 0; j < BW; ++j) {
+      const int32_t keep = left - 32 * j;
+      w[j] = keep >= 32 ? w[j] : (keep <= 0 ? 0u : w[j] & ((1u << (keep & 31)) - 1u));
+    }
+  }
+}
+
+// The final array of a sub-chunk -> X (padded), 32 elements per lane.  Returns the count or -1.
+// (out of line, with LDS-typed pointers: inlined, the 18 bit widths of this and of mark_run_starts4 in the
+// middle of the layer loop took the kernel to 300 registers; through generic pointers every access here
+// would be a flat_* one)
+__device__ __noinline__ int unpack_values4(const HC_LDS uint32_t* src, uint32_t nbytes, int bp, HC_LDS uint8_t* X, int lane)
+{
+  typedef const HC_LDS uint32_t* WordPtr;
+  uint32_t bw, fr, words = 0;
+  WordPtr data = src;
+  const int n = open_array4<4>(src, nbytes, bp, 1024u, bw, fr, data, words);
+  if (n <= 0)
+    return n;
+  const uint32_t blocks = ((uint32_t)n + 31u) >> 5;
+  HC_LDS uint32_t* const mine = reinterpret_cast<HC_LDS uint32_t*>(X + (uint32_t)lane * 132u);
+  auto go = [&](auto BWC) {
+    constexpr int BW = decltype(BWC)::value;
+    if ((uint32_t)lane < blocks) {
+      uint32_t w[BW == 0 ? 1 : BW];
+      load_words<BW>(data, words, (uint32_t)n, w, lane);
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        mine[k] = unpacked<BW>(w, k) + fr;
+    }
+  };
+  switch (bw) {
+#define HC_CASE(B) case B: go(std::integral_constant<int, B>{}); break;
+    HC_CASE(0) HC_CASE(1) HC_CASE(2) HC_CASE(3) HC_CASE(4) HC_CASE(5) HC_CASE(6) HC_CASE(7) HC_CASE(8)
+    HC_CASE(9) HC_CASE(10) HC_CASE(11) HC_CASE(12) HC_CASE(13) HC_CASE(14) HC_CASE(15) HC_CASE(16) HC_CASE(32)
+#undef HC_CASE
+  default: return -3; // (the bit widths 17 .. 31: unpack_values_wide4, from HBM)
+  }
+  return n;
+}
+
+// The final array of a sub-chunk at bit widths 17 .. 31 (a column that hardly compresses), an
+// element per lane, straight from HBM (what rounds 1-3 did for every width).  Returns the count or -1.
+__device__ __forceinline__ int unpack_values_wide4(
+    const HC_GLOBAL uint32_t* src, uint32_t nbytes, int bp, uint8_t* X, int lane)
+{
+  uint32_t bw, fr, words = 0;
+  const HC_GLOBAL uint32_t* data = src;
+  const int n = open_array4<4>(src, nbytes, bp, 1024u, bw, fr, data, words);
+  if (n <= 0)
+    return n;
+  const uint32_t last = words - 1;
+  for (uint32_t i = (uint32_t)lane; i < (uint32_t)n; i += kWave) {
+    const uint32_t bit = i * bw;
+    const uint32_t w0 = bit >> 5, sh = bit & 31u;
+    const uint64_t lo = (uint64_t)data[w0] | ((uint64_t)data[min(w0 + 1, last)] << 32);
+    *reinterpret_cast<uint32_t*>(X + x4_addr(i)) = ((uint32_t)(lo >> sh) & (uint32_t)((1ull << (bw & 63)) - 1ull)) + fr;
+  }
+  return n;
+}
+
+// The run lengths of a layer -> markers: run i (counted from 1) drops i at its start position, the
+// exclusive prefix sum of the lengths.  Returns the number of runs (-1: malformed), `total` = the
+// sum of the lengths.  The markers must have been zeroed.
+struct Runs4
+{
+  int n;          // number of runs; -1 / -2: malformed / too long; -3: take the element-per-lane code
+  uint32_t total; // sum of the lengths
+};
+__device__ __noinline__ Runs4 mark_run_starts4(
+    const HC_LDS uint32_t* src, uint32_t nbytes, int bp, HC_LDS uint16_t* marks, int lane)
+{
+  uint32_t total = 0; // (a local, returned by value: through a reference every use is a flat load)
+  typedef const HC_LDS uint32_t* WordPtr;
+  uint32_t bw, fr, words = 0;
+  WordPtr data = src;
+  const int n = open_array4<2>(src, nbytes, bp, 1024u, bw, fr, data, words);
+  if (n <= 0)
+    return Runs4{n, 0u};
+  fr &= 0xFFFFu;
+  // (lengths are 16-bit and x + FOR wraps there in the reference and the oracle: a frame of reference that
+  // could make one wrap is not an encoder's -- such a stream takes the element-per-lane code, -3)
+  if (fr + (bw >= 16 ? 0xFFFFu : (1u << bw) - 1u) > 0xFFFFu)
+    return Runs4{-3, 0u};
+  const uint32_t blocks = ((uint32_t)n + 31u) >> 5;
+  const bool active = (uint32_t)lane < blocks;
+  const uint32_t nv = active ? min((uint32_t)n - 32u * (uint32_t)lane, 32u) : 0u; // my runs
+  bool good = true;
+  auto go = [&](auto BWC) {
+    constexpr int BW = decltype(BWC)::value;
+    // my 32 lengths, then their running sums (behind the array's last run the bits read as 0: length =
+    // FOR there, taken off the lane's total again below)
+    uint32_t run[32];
+    if (active) {
+      uint32_t w[BW == 0 ? 1 : BW];
+      load_words<BW>(data, words, (uint32_t)n, w, lane);
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        run[k] = unpacked<BW>(w, k) + fr;
+#pragma unroll
+      for (int k = 1; k < 32; ++k)
+        run[k] += run[k - 1];
+    }
+    const uint32_t lane_total = active ? run[31] - (32u - nv) * fr : 0u;
+    const uint32_t incl = wave_scan_add_u32(lane_total);
+    total = read_lane(incl, 63);
+    if (total > 1024u) { // (runs longer than the sub-chunk: reference :1371-1380 would write past its buffer)
+      good = false;
+      return;
+    }
+    if (active) {
+      const uint32_t base = incl - lane_total;
+      // A marker is the PADDED index of the run's value in the element buffer, plus one (0: no run starts
+      // here): 33 lane + k + 1 for run 32 lane + k -- it grows with the run like the run's number does, and
+      // the expansion needs no address arithmetic.  The runs of mine behind the array's last run start at or
+      // behind `total`: their markers go to `total`, behind the output (see the layout note above).
+      const uint32_t first = 33u * (uint32_t)lane + 1u;
+      marks[base] = (uint16_t)first;
+#pragma unroll
+      for (int k = 1; k < 32; ++k)
+        marks[min(base + run[k - 1], total)] = (uint16_t)(first + (uint32_t)k);
+    }
+  };
+  switch (bw) {
+#define HC_CASE(B) case B: go(std::integral_constant<int, B>{}); break;
+    HC_CASE(0) HC_CASE(1) HC_CASE(2) HC_CASE(3) HC_CASE(4) HC_CASE(5) HC_CASE(6) HC_CASE(7) HC_CASE(8)
+    HC_CASE(9) HC_CASE(10) HC_CASE(11) HC_CASE(12)
+#undef HC_CASE
+  default: return Runs4{-3, 0u}; // (run lengths of a 1024-element sub-chunk need 11 bits at most: wider ones, 13 .. 16, element by element)
+  }
+  return Runs4{good ? n : -2, total};
+}
+
 template <int S>
 __device__ __forceinline__ void cascaded_decode_partition(
     const uint8_t* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes_arr,
     const size_t* __restrict__ out_caps, uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
     hipcompStatus_t* __restrict__ statuses, const size_t part, uint8_t* const smem, const int lane);
 
+__device__ __forceinline__ void cascaded_decode_partition4(
+    const uint8_t* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes_arr,
+    const size_t* __restrict__ out_caps, uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
+    hipcompStatus_t* __restrict__ statuses, const size_t part, uint8_t* const smem, const int lane);
+
+// (launch bound: 4 waves per SIMD where LDS lets a CU hold 14 of these one-wave workgroups, 5 for the
+// 4-byte fast path, which holds 21)
+#ifndef HC_CASC_DEC_OCC
+#define HC_CASC_DEC_OCC 5
+#endif
 template <int S>
-__global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
+__global__ __launch_bounds__(kWave, S == 4 ? HC_CASC_DEC_OCC : 4) void cascaded_decompress_kernel(
     const uint8_t* const* __restrict__ comp_ptrs,
     const size_t* __restrict__ comp_bytes_arr,
     const size_t* __restrict__ out_caps, const size_t batch,
@@ -1154,10 +1385,372 @@ __global__ __launch_bounds__(kWave) void cascaded_decompress_kernel(
                  : ((S == 1 && type <= 1) || (S == 2 && (type == 2 || type == 3))
                     || (S == 4 && (type == 4 || type == 5)) || (S == 8 && (type == 6 || type == 7)));
     }
-    for (uint64_t todo = wave_ballot(mine); todo != 0; todo &= todo - 1)
-      cascaded_decode_partition<S>(comp_ptrs, comp_bytes_arr, out_caps, out_ptrs, actual_bytes, statuses,
-                                   first + (size_t)__builtin_ctzll(todo) * waves, smem, lane);
+    for (uint64_t todo = wave_ballot(mine); todo != 0; todo &= todo - 1) {
+      const size_t part = first + (size_t)__builtin_ctzll(todo) * waves;
+      if constexpr (S == 4)
+        cascaded_decode_partition4(comp_ptrs, comp_bytes_arr, out_caps, out_ptrs, actual_bytes, statuses, part, smem, lane);
+      else
+        cascaded_decode_partition<S>(comp_ptrs, comp_bytes_arr, out_caps, out_ptrs, actual_bytes, statuses, part, smem, lane);
+    }
   }
+}
+
+// One partition of 4-byte elements, by one wave: the fast path.
+__device__ __forceinline__ void cascaded_decode_partition4(
+    const uint8_t* const* __restrict__ comp_ptrs, const size_t* __restrict__ comp_bytes_arr,
+    const size_t* __restrict__ out_caps, uint8_t* const* __restrict__ out_ptrs, size_t* __restrict__ actual_bytes,
+    hipcompStatus_t* __restrict__ statuses, const size_t part, uint8_t* const smem, const int lane)
+{
+  constexpr int S = 4;
+  constexpr uint32_t CE = 1024;
+  cgptr comp = to_global(uniform_ptr(comp_ptrs[part]));
+  const size_t comp_bytes64 = uniform((uint64_t)comp_bytes_arr[part]);
+  const bool bad_header = comp == nullptr || comp_bytes64 < kPartMeta;
+  uint32_t type = 0xFFu, byte2 = 0;
+  if (!bad_header) {
+    type = uniform((uint32_t)comp[3]);
+    byte2 = uniform((uint32_t)comp[2]);
+  }
+  const bool undecodable = bad_header || type > 7 || (byte2 >> 4) != 0;
+  auto finish = [&](bool ok, uint32_t bytes) {
+    if (lane == 0) {
+      actual_bytes[part] = ok ? bytes : 0;
+      statuses[part] = ok ? hipcompSuccess : hipcompErrorCannotDecompress;
+    }
+  };
+  if (undecodable) {
+    finish(false, 0);
+    return;
+  }
+  const uint32_t comp_bytes = (uint32_t)comp_bytes64;
+  const uint32_t hdr = uniform(*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp));
+  const int R = (int)(hdr & 0xFFu), D = (int)((hdr >> 8) & 0xFFu), bp = (int)((hdr >> 16) & 0x0Fu);
+  const uint32_t ub = uniform(*reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + 4));
+  const uint32_t N = ub / S;
+  gptr out = to_global(uniform_ptr(out_ptrs[part]));
+  if (uniform((uint64_t)out_caps[part]) < (size_t)N * S) { // reference :1214-1223
+    finish(false, 0);
+    return;
+  }
+  if (R == 0 && D == 0 && bp == 0) { // raw partition (reference :1225-1254)
+    if (comp_bytes < kPartMeta + N * S) {
+      finish(false, 0);
+      return;
+    }
+    wave_copy(out, comp + kPartMeta, N * S, lane);
+    finish(true, N * S);
+    return;
+  }
+  const uint32_t msz = chunk_metadata_size<S>(R, D);
+  if (R > 7 || msz > 64) {
+    finish(false, 0);
+    return;
+  }
+  uint32_t* const stage = reinterpret_cast<uint32_t*>(smem + kDec4Stage);
+  uint8_t* const X = smem + kDec4X;
+  uint16_t* const marks = reinterpret_cast<uint16_t*>(smem + kDec4Marks);
+
+  const uint32_t end_w = comp_bytes / 4;
+  const uint32_t dh_word = (uint32_t)(R + 2); // the delta heads follow the R + 2 size words (4-byte elements: no padding)
+  const int layers = R > D ? R : D;
+  uint32_t pos = kPartMeta, done = 0;
+  bool ok = true;
+  uint32_t pf[kStagePerLane];
+  auto prefetch = [&](uint32_t p) {
+    const HC_GLOBAL uint32_t* w = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + p);
+    const uint32_t avail = end_w - p / 4;
+#pragma unroll
+    for (int k = 0; k < (int)kStagePerLane; ++k) {
+      const uint32_t idx = (uint32_t)lane + (uint32_t)k * kWave;
+      pf[k] = w[min(idx, avail - 1)];
+    }
+  };
+  if (pos / 4 < end_w)
+    prefetch(pos);
+  while (pos / 4 < end_w) { // reference :1268
+    if ((pos + msz) / 4 > end_w) {
+      ok = false;
+      break;
+    }
+#pragma unroll
+    for (int k = 0; k < (int)kStagePerLane; ++k)
+      stage[lane + k * kWave] = pf[k];
+    // the chunk metadata (the first 16 words of the staged image at most) in a register, lane j = word j:
+    // the staged image may be given up for an array that lies outside it (below)
+    const uint32_t img = pf[0];
+    auto meta_at = [&](uint32_t j) -> uint32_t { return read_lane(img, (int)j); };
+    const uint32_t csz = meta_at(0);
+    if (csz < 4 || csz > comp_bytes - pos) { // (see the generic decoder)
+      ok = false;
+      break;
+    }
+    const uint32_t next_pos = pos + (csz / 4) * 4; // reference :1412-1413
+    if (next_pos / 4 < end_w)
+      prefetch(next_pos);
+    // array offsets inside the chunk (reference :1291-1305)
+    uint32_t offs_final = 0;
+    for (int i = 0; i < R; ++i)
+      offs_final = ru(offs_final + meta_at((uint32_t)i + 1u), 4u);
+    bool staged = true; // the staged image still holds the head of the sub-chunk
+    // bounds of an array at byte offset `rel` of the sub-chunk (reference block_read :712-713)
+    auto inside = [&](uint32_t rel, uint32_t nbytes) { return !(((pos + rel) & 3u) || (pos + rel + ru(nbytes, 4)) / 4 > end_w); };
+    // `count` words from HBM to LDS
+    auto fetch = [&](uint32_t* dst, uint32_t rel, uint32_t count) {
+      const HC_GLOBAL uint32_t* g = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + pos + rel);
+      for (uint32_t i = (uint32_t)lane; i < count; i += kWave)
+        dst[i] = g[i];
+      lds_lane_exchange_fence();
+    };
+    // ---- the final array -> X
+    int n = -1;
+    {
+      const uint32_t rel = msz + offs_final, nbytes = meta_at(1u + (uint32_t)R);
+      if (inside(rel, nbytes)) {
+        if (rel + ru(nbytes, 4) <= kStageWords * 4) {
+          n = unpack_values4((const HC_LDS uint32_t*)(stage + rel / 4), nbytes, bp, (HC_LDS uint8_t*)X, lane);
+        } else {
+          // outside the staged image: its words (1026 at most are looked at) into X itself, unpacked in
+          // place -- a lane's loads come before its stores, and so do the wave's
+          fetch(reinterpret_cast<uint32_t*>(X), rel, min((nbytes + 3u) / 4u, 1026u));
+          n = unpack_values4((const HC_LDS uint32_t*)X, nbytes, bp, (HC_LDS uint8_t*)X, lane);
+        }
+        if (n == -3) // a bit width of 17 .. 31
+          n = unpack_values_wide4(reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + pos + rel), nbytes, bp, X, lane);
+      }
+    }
+    if (n < 0) {
+      ok = false;
+      break;
+    }
+    lds_lane_exchange_fence();
+    bool stored = false;
+    int fused_delta = -1;
+    for (int l = layers - 1; l >= 0 && ok; --l) {
+      if (l < D && l != fused_delta) { // reference block_delta_decompress :343-377, standalone
+        if ((uint32_t)n + 1 > CE) {
+          ok = false;
+          break;
+        }
+        // x[0] = head, x[i + 1] = x[i] + old x[i], in place: every lane has its 16 elements in registers
+        // before any lane stores (the sums move one element on: the last one of the lane below comes by DPP)
+        const uint32_t carry = meta_at(dh_word + (uint32_t)l);
+        {
+          const uint32_t pos0 = (uint32_t)lane * 16u;
+          uint32_t v[16];
+          uint32_t* px = reinterpret_cast<uint32_t*>(X + x4_addr(pos0));
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            v[k] = px[k];
+          lds_lane_exchange_fence();
+#pragma unroll
+          for (int k = 1; k < 16; ++k)
+            v[k] += v[k - 1];
+          const uint32_t incl = wave_scan_add_u32(v[15]);
+          const uint32_t base = carry + incl - v[15];
+          const uint32_t first = from_lane_below(base + v[15], carry, lane);
+          if (pos0 <= (uint32_t)n) {
+            px[0] = first;
+#pragma unroll
+            for (int k = 1; k < 16; ++k)
+              px[k] = base + v[k - 1];
+          }
+        }
+        lds_lane_exchange_fence();
+        ++n;
+      }
+      if (l < R) { // reference block_rle_decompress :255-305
+        uint32_t o = 0;
+        for (int i = 0; i < l; ++i)
+          o = ru(o + meta_at((uint32_t)i + 1u), 4u);
+        {
+          u32x4 z = {0, 0, 0, 0};
+          u32x4* mz = reinterpret_cast<u32x4*>(marks);
+          mz[lane] = z;
+          mz[lane + kWave] = z;
+        }
+        lds_lane_exchange_fence();
+        uint32_t total = 0;
+        {
+          const uint32_t rel = msz + o, nbytes = meta_at((uint32_t)l + 1u);
+          int m = -1;
+          if (inside(rel, nbytes)) {
+            // the array's words: in the staged image, or staged now in its place if they fit it
+            const uint32_t need = ru(nbytes, 4);
+            uint32_t at = ~0u; // word of `stage` the array begins at
+            if (staged && rel + need <= kStageWords * 4) {
+              at = rel / 4;
+            } else if (need <= kStageWords * 4) {
+              fetch(stage, rel, need / 4);
+              staged = false;
+              at = 0;
+            }
+            // the element-per-lane form (rounds 1-3), for what the blocked one does not take
+            uint32_t carry = 0;
+            bool too_long = false;
+            auto run_starts = [&](auto words) {
+              ArrayReader<uint16_t, decltype(words)> lengths;
+              const int mm = lengths.open(words, nbytes, bp, CE);
+              if (mm < 0)
+                return mm;
+              for (uint32_t b0 = 0; b0 < (uint32_t)mm; b0 += kWave) {
+                const uint32_t i = b0 + (uint32_t)lane;
+                const uint32_t cv = i < (uint32_t)mm ? (uint32_t)lengths.get(i) : 0u;
+                const uint32_t incl = wave_scan_add_u32(cv);
+                const uint32_t start = carry + incl - cv;
+                carry += read_lane(incl, 63);
+                if (i < (uint32_t)mm && start < CE)
+                  marks[start] = (uint16_t)(i + (i >> 5) + 1u); // (the padded index of the run's value, plus one)
+                too_long = too_long || carry > CE;
+              }
+              return mm;
+            };
+            if (at != ~0u) {
+              const Runs4 runs = mark_run_starts4((const HC_LDS uint32_t*)(stage + at), nbytes, bp, (HC_LDS uint16_t*)marks, lane);
+              m = runs.n;
+              total = runs.total;
+              if (m == -3) { // a frame of reference that could wrap a 16-bit length, a width of 13 .. 16 bits
+                m = run_starts(static_cast<const uint32_t*>(stage + at));
+                total = carry;
+                if (too_long)
+                  m = -2;
+              }
+            } else { // an array of run lengths larger than the staged image (1 KiB): from HBM
+              m = run_starts(reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + pos + rel));
+              total = carry;
+              if (too_long)
+                m = -2;
+            }
+          }
+          if (m < 0 || m != n) {
+            ok = false;
+            break;
+          }
+        }
+        lds_lane_exchange_fence();
+        const bool with_delta = l >= 1 && (l - 1) < D; // next op: delta of layer l-1
+        // (the last expansion of a sub-chunk could store straight to HBM, and did until the stores were
+        // looked at: a lane's 16 consecutive elements are four 16-byte stores that each touch 64 different
+        // lines, 256 partial-line writes per sub-chunk -- through the element buffer and out again
+        // lane-per-element they are 4 fully coalesced ones)
+        const bool to_hbm = false;
+        if (with_delta && total + 1 > CE) {
+          ok = false;
+          break;
+        }
+        if (to_hbm && done + total > N) { // reference :1395-1402
+          ok = false;
+          break;
+        }
+        uint32_t head = 0;
+        if (with_delta)
+          head = meta_at(dh_word + (uint32_t)(l - 1));
+        gptr gdst = out + (size_t)done * S;
+        // the expansion: one round of 64 lanes x 16 consecutive output elements (see the generic decoder),
+        // in place: the values of the runs are read (all lanes) before anything is stored
+        {
+          const uint32_t pos0 = (uint32_t)lane * 16u;
+          uint32_t mk[16];
+          {
+            const u32x4* mp = reinterpret_cast<const u32x4*>(marks + pos0);
+            const u32x4 t0 = mp[0], t1 = mp[1];
+            const uint32_t w[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+              mk[k] = (k & 1) ? w[k / 2] >> 16 : w[k / 2] & 0xFFFFu;
+          }
+          // (behind `total` there is nothing but the markers of runs behind the array's last one: whatever
+          // they make of the elements behind `total` is not stored, and every marker is an index inside X)
+          uint32_t r[16];
+          r[0] = mk[0];
+#pragma unroll
+          for (int k = 1; k < 16; ++k)
+            r[k] = max(r[k - 1], mk[k]);
+          const uint32_t upto = wave_scan_max_u32(r[15]);
+          const uint32_t below = max(1u, dpp_u32<0x138, 0xF>(upto)); // (>= 1: the lanes behind `total` read x[0])
+          uint32_t v[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            v[k] = *reinterpret_cast<const uint32_t*>(X + 4u * (max(r[k], below) - 1u));
+          lds_lane_exchange_fence();
+          if (with_delta) {
+#pragma unroll
+            for (int k = 1; k < 16; ++k)
+              v[k] += v[k - 1];
+            const uint32_t incl = wave_scan_add_u32(v[15]);
+            const uint32_t base = head + incl - v[15];
+            const uint32_t first = from_lane_below(base + v[15], head, lane);
+            if (pos0 <= total) {
+              uint32_t* py = reinterpret_cast<uint32_t*>(X + x4_addr(pos0));
+              py[0] = first;
+#pragma unroll
+              for (int k = 1; k < 16; ++k)
+                py[k] = base + v[k - 1];
+            }
+          } else if (to_hbm) {
+            if (pos0 + 16u <= total) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                u32x4 t = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+                *reinterpret_cast<HC_GLOBAL u32x4_unaligned*>(gdst + (size_t)pos0 * S + 16u * i) = t;
+              }
+            } else if (pos0 < total) {
+#pragma unroll
+              for (int k = 0; k < 16; ++k)
+                if (pos0 + (uint32_t)k < total)
+                  reinterpret_cast<HC_GLOBAL uint32_t*>(gdst)[pos0 + k] = v[k];
+            }
+          } else {
+            if (pos0 < total) {
+              uint32_t* py = reinterpret_cast<uint32_t*>(X + x4_addr(pos0));
+#pragma unroll
+              for (int k = 0; k < 16; ++k)
+                py[k] = v[k];
+            }
+          }
+        }
+        lds_lane_exchange_fence();
+        if (with_delta) {
+          fused_delta = l - 1;
+          n = (int)total + 1;
+        } else {
+          n = (int)total;
+        }
+        stored = to_hbm;
+      }
+    }
+    if (!ok)
+      break;
+    if (!stored) {
+      if (done + (uint32_t)n > N) { // reference :1395-1402
+        ok = false;
+        break;
+      }
+      // sub-chunk -> output (outputs are 4-byte aligned: cascaded.h:178-193): four consecutive elements
+      // per lane and step (they lie in one block of the padded layout), 1 KiB per store instruction
+      HC_GLOBAL uint32_t* dst = reinterpret_cast<HC_GLOBAL uint32_t*>(out + (size_t)done * S);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t e = 4u * ((uint32_t)lane + 64u * q);
+        if (256u * q < (uint32_t)n) { // (wave-uniform)
+          const uint32_t* px = reinterpret_cast<const uint32_t*>(X + x4_addr(e));
+          if (e + 4u <= (uint32_t)n) {
+            u32x4 t = {px[0], px[1], px[2], px[3]};
+            *reinterpret_cast<HC_GLOBAL u32x4_unaligned*>(dst + e) = t;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (e + (uint32_t)k < (uint32_t)n)
+                dst[e + k] = px[k];
+          }
+        }
+      }
+    }
+    done += (uint32_t)n;
+    pos = next_pos;
+  }
+  if (done != N)
+    ok = false;
+  finish(ok, N * S);
 }
 
 // One partition, by one wave (the launch that owns its width).
@@ -1507,10 +2100,26 @@ hipError_t launch_decompress(
   DecompressKernel k = cascaded_decompress_kernel<S>;
   constexpr uint32_t lds = dec_lds_bytes<S>();
   static_assert(lds <= 64 * 1024, "fits the default dynamic LDS limit: no attribute to raise");
-  // as many one-wave workgroups as the chip holds with this much LDS each (handed out in 1280-byte granules)
-  uint32_t per_cu = (160u * 1024u) / ((lds + 1279u) / 1280u * 1280u);
-  if (per_cu > 32)
-    per_cu = 32;
+  // As many one-wave workgroups as the chip holds at once -- LDS (handed out in 1280-byte granules) or
+  // registers, whichever is short first: every wave takes the same number of partitions, so a
+  // workgroup that has to wait for a slot makes the launch twice as long (met in round 4: 21 by LDS,
+  // 20 by registers, 5376 workgroups launched, 12.8 waves per CU at work on average).
+  static std::atomic<int> g_per_cu[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int cached = dev >= 0 && dev < 16 ? g_per_cu[dev].load(std::memory_order_acquire) : 0;
+  if (cached == 0) {
+    int by_api = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&by_api, reinterpret_cast<const void*>(k), kWave, lds) != hipSuccess || by_api < 1)
+      by_api = 1;
+    const int by_lds = (int)((160u * 1024u) / ((lds + 1279u) / 1280u * 1280u));
+    cached = by_api < by_lds ? by_api : by_lds;
+    if (cached > 32)
+      cached = 32;
+    if (dev >= 0 && dev < 16)
+      g_per_cu[dev].store(cached, std::memory_order_release);
+  }
+  const uint32_t per_cu = (uint32_t)cached;
   const size_t resident = (size_t)num_cus_of_current_device() * per_cu;
   k<<<dim3((unsigned)(batch < resident ? batch : resident)), dim3(kWave), lds, stream>>>(
       comp_ptrs, comp_bytes, out_caps, batch, out_ptrs, actual_bytes, statuses);

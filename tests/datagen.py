@@ -271,3 +271,60 @@ def runs_of_elements(seed: int, n_bytes: int, elem_size: int, longest: int = 16)
     dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[elem_size]
     values = np.arange(len(lengths), dtype=np.uint64).astype(dt)
     return np.repeat(values, lengths)[: n_bytes // elem_size].tobytes()
+
+
+def lane63_case(elem_size: int, layout: int, seed: int = 0):
+    """A chunk crafted for the LZ4 encoder's several-sequences trips at a span of 64 lanes (lz4_far.hiph,
+    pick() and the chain walk): a trip whose last sequence ends BEHIND lane 63 while lane 63 itself has a
+    table match.  Elements of `elem_size` bytes.
+      layout 1  trip = [1 literal][k short matches][l literals][match A from lane p, q elements, p + q > 64]:
+                lane 63's word lies inside A, whose first occurrence went into the table -- bit 63 of the
+                trip's match mask is set while the next window starts beyond lane 63 (the general walk)
+      layout 2  trip = [k short matches][match A ending at lane 62][match B AT lane 63]: a chain of
+                sequences without literals that runs through lane 63 (the chain walk)
+    The strings are planted in a match-less prefix first (none of their elements at window lane 31,
+    which the reference never inserts), each followed by an element of its own.
+    Returns (bytes, expected sequences as (literal bytes, match bytes) behind the first one)."""
+    S = elem_size
+    rng = np.random.default_rng(1000 * S + 10 * layout + seed)
+    NV = {1: 61, 2: 63, 4: 64}[S]
+    used = set()
+
+    def uniq(n):
+        out = []
+        while len(out) < n:
+            v = int(rng.integers(1, 1 << (8 * S)))
+            if S == 1 or v not in used:
+                used.add(v)
+                out.append(v)
+        return out
+    m = {1: 8, 2: 4, 4: 2}[S]  # a short match: 8 bytes
+    if layout == 1:
+        k, l, q = {1: (6, 3, 15), 2: (14, 1, 7), 4: (30, 1, 3)}[S]
+    else:
+        k, q, r = {1: (6, 15, 8), 2: (14, 7, 4), 4: (30, 3, 2)}[S]
+    strings = [uniq(m) for _ in range(k + 1)] + [uniq(q)] + ([uniq(r)] if layout == 2 else [])
+    pre = []
+    for s_ in strings:
+        pre += uniq(3)
+        while any((len(pre) + j) % NV == 31 for j in range(len(s_))):
+            pre += uniq(1)
+        pre += s_ + uniq(1)
+    pre += uniq(2 * NV)
+    while len(pre) % NV:
+        pre += uniq(1)
+    Ms, A = strings[:k + 1], strings[k + 1]
+    region = list(Ms[0])
+    if layout == 1:
+        region += uniq(1)
+        for M in Ms[1:]:
+            region += M
+        region += uniq(l) + A + uniq(40)
+        want = [(S, m * S)] + [(0, m * S)] * (k - 1) + [(l * S, q * S)]
+    else:
+        for M in Ms[1:]:
+            region += M
+        region += A + strings[k + 2] + uniq(40)
+        want = [(0, m * S)] * k + [(0, q * S), (0, r * S)]
+    els = pre + region + uniq(200)
+    return np.array(els, dtype={1: np.uint8, 2: np.uint16, 4: np.uint32}[S]).tobytes(), want

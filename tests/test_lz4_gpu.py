@@ -590,3 +590,60 @@ def test_chains_of_sequences_without_literals(hc, oracle, reflib, cuda, lz4_shap
         assert got[i] == want[i % len(base)], f"chunk {i} ({len(chunks[i])} bytes) {tname} shape={lz4_shape}: kernel != oracle"
     _round_trip(hc, mine, chunks, dtype)
     compare_with_reference(reflib, "chains of sequences without literals", _reference_agrees(hc, base, dtype, 65536, want, tname))
+
+
+def _sequences(blk: bytes):
+    """(literal bytes, match bytes) of every sequence of an LZ4 block"""
+    i, out, n = 0, [], len(blk)
+    while i < n:
+        tok = blk[i]; i += 1
+        lit = tok >> 4
+        if lit == 15:
+            while True:
+                b = blk[i]; i += 1; lit += b
+                if b != 255:
+                    break
+        i += lit
+        if i >= n:
+            out.append((lit, 0))
+            break
+        i += 2
+        ml = (tok & 15) + 4
+        if (tok & 15) == 15:
+            while True:
+                b = blk[i]; i += 1; ml += b
+                if b != 255:
+                    break
+        out.append((lit, ml))
+    return out
+
+
+@pytest.mark.parametrize("tname,dtype,es", TYPES)
+def test_match_at_lane_63_with_the_next_window_beyond_it(hc, oracle, reflib, cuda, lz4_shape, tname, dtype, es):
+    """The several-sequences trips of the far kernels at a span of 64 lanes (the dense class, and every
+    wave with its table in LDS): a trip whose last sequence ends BEHIND lane 63 while lane 63 itself
+    has a table match -- bit 63 of the trip's match mask set with `start` > 63 (pick(), lz4_far.hiph:
+    nothing may be taken twice) -- and a chain of sequences without literals that runs through lane 63
+    (the chain walk).  tests/datagen.py:lane63_case crafts both; that the oracle's stream has exactly
+    the crafted sequences is asserted here, so the windows fall where the case wants them.  A few chunks
+    (one wave each, its table in LDS: span 64 whatever the class) and many (all kinds of waves)."""
+    cases = []
+    for layout in (1, 2):
+        found = 0
+        for seed in range(40):
+            data, want_seqs = datagen.lane63_case(es, layout, seed)
+            z = _want(oracle, data, es, 65536)
+            if _sequences(z)[1:1 + len(want_seqs)] == want_seqs:
+                cases.append(data)
+                found += 1
+                if found == 3:
+                    break
+        assert found == 3, (es, layout)
+    for chunks in (cases, cases * 700):
+        src, mine = _compress(hc, chunks, dtype, 65536)
+        got = mine.to_host_chunks()
+        want = [_want(oracle, c, es, 65536) for c in chunks]
+        for i in range(len(chunks)):
+            assert got[i] == want[i], f"chunk {i} {tname} shape={lz4_shape}: kernel != oracle"
+        _round_trip(hc, mine, chunks, dtype)
+    compare_with_reference(reflib, "lane 63", _reference_agrees(hc, cases, dtype, 65536, [_want(oracle, c, es, 65536) for c in cases], tname))

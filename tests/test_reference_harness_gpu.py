@@ -28,3 +28,23 @@ def test_reference_c_harness_passes_on_the_product_library(cuda, name):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "failed" not in r.stdout.lower(), r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("name", ["test_cascaded_batch", "test_lz4", "test_random_lz4", "test_cascaded"])
+def test_reference_cpp_tests_pass_on_the_product_library(cuda, name):
+    """The reference's C++ callers: tests/test_cascaded_batch.cpp (the batched Cascaded C API with the
+    wire-layout known answers of verify_compression_output, :213-379, all element types),
+    tests/test_lz4.cpp and tests/test_random_lz4.cpp (LZ4Manager through hipcomp/lz4.hpp),
+    tests/test_cascaded.cpp (CascadedManager through hipcomp/cascaded.hpp) -- Catch programs compiled
+    UNCHANGED from where they lie against this repo's include/ and linked with the product library
+    (oracle/Makefile: _ref/cpp_*).  They must exit 0 with every assertion passed."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "cpp_" + name)
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} absent (built by oracle/Makefile where /root/reference exists)")
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    bound = [ln for ln in ldd.splitlines() if "libhipcomp.so" in ln]
+    assert bound and os.path.realpath(bound[0].split("=>")[1].split("(")[0].strip()) == os.path.realpath(
+        os.path.join(ROOT, "hipcomp-core_amd", "lib", "libhipcomp.so")), ldd
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "All tests passed" in r.stdout, r.stdout[-2000:]

@@ -409,6 +409,19 @@ extern "C" int hipcompBatchedLZ4DebugTripLog(uint32_t* host_words, uint32_t* cou
 }
 #endif
 
+#ifdef HC_DEC_STAMPS
+// (diagnostic build only; the name makes it pass the export map)
+extern "C" int hipcompBatchedLZ4DebugDecodeStamps(unsigned long long* host8, int reset)
+{
+  unsigned long long zeros[8] = {};
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_dec_stamps), sizeof(zeros)) != hipSuccess)
+    return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_dec_stamps), zeros, sizeof(zeros)) != hipSuccess)
+    return 2;
+  return 0;
+}
+#endif
+
 size_t lz4_compress_temp_bytes_used(uint32_t ht_size, size_t batch)
 {
   // header, the four class lists, alignment, one table per chunk but no more than the chip holds waves

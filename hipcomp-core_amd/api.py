@@ -139,6 +139,26 @@ class HipcompLibrary:
             raise RuntimeError(f"hipcompBatched{codec}CompressGetMaxOutputChunkSize -> status {st}")
         return out.value
 
+    def cascaded_select_opts(self, ptrs: int, sizes: int, batch: int, type_tag: int, temp: int, temp_bytes: int, stream: int = 0):
+        """hipcompBatchedCascadedSelectOpts (include/hipcomp/cascaded_select.h, an API of this library's own):
+        -> (CascadedOpts, estimated ratio).  Synchronises the stream."""
+        fn = self._dll.hipcompBatchedCascadedSelectOpts
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, POINTER(CascadedOpts), POINTER(ctypes.c_double), c_void_p]
+        opts, ratio = CascadedOpts(), ctypes.c_double(0.0)
+        st = fn(ptrs, sizes, batch, type_tag, temp, temp_bytes, ctypes.byref(opts), ctypes.byref(ratio), stream)
+        if st != 0:
+            raise RuntimeError(f"hipcompBatchedCascadedSelectOpts -> status {st}")
+        return opts, ratio.value
+
+    def cascaded_select_temp_size(self) -> int:
+        out = c_size_t(0)
+        fn = self._dll.hipcompBatchedCascadedSelectOptsGetTempSize
+        fn.restype = c_int
+        fn.argtypes = [POINTER(c_size_t)]
+        assert fn(ctypes.byref(out)) == 0
+        return out.value
+
     def decompress_temp_size(self, codec: str, num_chunks: int, max_chunk: int) -> int:
         out = c_size_t(0)
         st = getattr(self, f"hipcompBatched{codec}DecompressGetTempSize")(num_chunks, max_chunk, ctypes.byref(out))

@@ -2175,4 +2175,56 @@ void cascaded_launch_get_sizes(
       comp_ptrs, comp_bytes, out_sizes, batch);
 }
 
+
+// ---- hipcomp/cascaded_select.h: the sample of a batch, and the totals per candidate ----------
+namespace {
+
+__global__ __launch_bounds__(64) void cascaded_select_sample_kernel(
+    const uint8_t* const* __restrict__ in_ptrs, const size_t* __restrict__ in_bytes, const size_t batch,
+    const size_t parts, const size_t clip, const int elem_size, const uint8_t** __restrict__ s_in_ptrs,
+    size_t* __restrict__ s_in_bytes, uint8_t** __restrict__ s_out_ptrs, uint8_t* __restrict__ slots, const size_t slot_bytes)
+{
+  const size_t j = threadIdx.x;
+  if (j >= parts)
+    return;
+  const size_t p = j * batch / parts; // spread evenly over the batch
+  size_t n = in_bytes[p];
+  n = n < clip ? n : clip;
+  n = n / (size_t)elem_size * (size_t)elem_size;
+  s_in_ptrs[j] = in_ptrs[p];
+  s_in_bytes[j] = in_ptrs[p] ? n : 0;
+  s_out_ptrs[j] = slots + j * slot_bytes;
+}
+
+__global__ __launch_bounds__(64) void cascaded_select_totals_kernel(
+    const size_t* __restrict__ s_in_bytes, const size_t* __restrict__ s_out_bytes, const size_t parts,
+    const size_t candidates, const size_t stride, unsigned long long* __restrict__ totals)
+{
+  const size_t c = threadIdx.x;
+  if (c > candidates)
+    return;
+  unsigned long long sum = 0;
+  for (size_t j = 0; j < parts; ++j)
+    sum += c < candidates ? s_out_bytes[c * stride + j] : s_in_bytes[j]; // (the last entry: the uncompressed bytes)
+  totals[c] = sum;
+}
+
+} // namespace
+
+void cascaded_launch_select_sample(
+    const uint8_t* const* in_ptrs, const size_t* in_bytes, size_t batch, size_t parts, size_t clip, int elem_size,
+    const uint8_t** s_in_ptrs, size_t* s_in_bytes, uint8_t** s_out_ptrs, uint8_t* slots, size_t slot_bytes,
+    hipStream_t stream)
+{
+  cascaded_select_sample_kernel<<<dim3(1), dim3(64), 0, stream>>>(
+      in_ptrs, in_bytes, batch, parts, clip, elem_size, s_in_ptrs, s_in_bytes, s_out_ptrs, slots, slot_bytes);
+}
+
+void cascaded_launch_select_totals(
+    const size_t* s_in_bytes, const size_t* s_out_bytes, size_t parts, size_t candidates, size_t stride,
+    unsigned long long* totals, hipStream_t stream)
+{
+  cascaded_select_totals_kernel<<<dim3(1), dim3(64), 0, stream>>>(s_in_bytes, s_out_bytes, parts, candidates, stride, totals);
+}
+
 } // namespace hcamd

@@ -63,8 +63,12 @@ def test_library_exports_exactly_the_declared_abi(hc):
     assert len(interop) == 3 and interop <= exported
     hlif = _declared_hlif()
     assert len(hlif) == 12 and hlif <= exported
+    # this library's own extension of the batched Cascaded API (include/hipcomp/cascaded_select.h; the header says so)
+    select = set(re.findall(r"hipcompStatus_t\s+(hipcompBatchedCascadedSelect\w+)\s*\(",
+                            open(os.path.join(ROOT, "include", "hipcomp", "cascaded_select.h")).read()))
+    assert select == {"hipcompBatchedCascadedSelectOpts", "hipcompBatchedCascadedSelectOptsGetTempSize"} and select <= exported
     others = {e for e in exported if not e.startswith("hipcomp::") and not e.startswith(("vtable for", "typeinfo"))}
-    assert others <= declared | prims | interop | hlif, sorted(others - declared - prims - interop - hlif)
+    assert others <= declared | prims | interop | hlif | select, sorted(others - declared - prims - interop - hlif - select)
 
 
 def test_headers_compile_as_c(tmp_path):

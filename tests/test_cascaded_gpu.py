@@ -181,3 +181,49 @@ def test_chunk_size_is_ignored_as_in_the_reference(hc, oracle, reflib, cuda):
             got = hc.batch.Codec("Cascaded", hc.CascadedOpts(cb, 5, 2, 1, 1), lib=reflib).compress(src).to_host_chunks()[0]
             assert oracle.masked_equal(got, want, mask)
     compare_with_reference(reflib, "chunk_size ignored", check)
+
+
+def test_option_selector_picks_what_measures_smallest(hc, cuda):
+    """hipcomp/cascaded_select.h (an API of this library's own: the reference has no selector for the
+    batched interface): the options it returns compress the WHOLE batch within 2 % of the best of its
+    candidate sets, on columns with different characters -- sorted keys with repeats (RLE + delta),
+    a low-cardinality dimension column (RLE alone), small random integers (bit-packing alone), and
+    full-range random words (nothing helps: no compression)."""
+    import torch
+    rng = np.random.default_rng(11)
+    n, per = 256, 16384
+    columns = {
+        "sorted": np.stack([np.cumsum(rng.integers(0, 4, per) * rng.integers(1, 9, per)) + rng.integers(0, 1 << 20)
+                            for _ in range(n)]).astype(np.uint32),
+        "dimension": np.stack([np.repeat(rng.integers(0, 50, per // 16), 16) for _ in range(n)]).astype(np.uint32),
+        "small": rng.integers(0, 1000, (n, per)).astype(np.uint32),
+        "random": rng.integers(0, 1 << 32, (n, per), dtype=np.uint64).astype(np.uint32),
+    }
+    lib = hc.default_library()
+    candidates = [(0, 0, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 1), (2, 0, 1), (0, 2, 1), (2, 1, 1), (1, 2, 1), (2, 2, 1)]
+    picked = {}
+    for name, col in columns.items():
+        src = hc.batch.from_host_chunks([row.tobytes() for row in col], "cuda:0")
+        temp = torch.empty(lib.cascaded_select_temp_size(), dtype=torch.uint8, device="cuda:0")
+        opts, ratio = lib.cascaded_select_opts(src.ptrs.data_ptr(), src.sizes.data_ptr(), src.n, hc.hipcompType.UINT,
+                                               temp.data_ptr(), temp.numel(), torch.cuda.current_stream().cuda_stream)
+        assert opts.chunk_size == 4096 and opts.type == hc.hipcompType.UINT
+        sizes = {}
+        for R, D, bp in candidates:
+            comp = hc.batch.Codec("Cascaded", hc.CascadedOpts(4096, hc.hipcompType.UINT, R, D, bp)).compress(src)
+            sizes[(R, D, bp)] = int(comp.sizes.sum().item())
+        mine = (opts.num_RLEs, opts.num_deltas, opts.use_bp)
+        picked[name] = mine
+        assert mine in sizes, mine
+        assert sizes[mine] <= 1.02 * min(sizes.values()), (name, mine, sizes)
+        assert abs(ratio - src.sizes.sum().item() / sizes[mine]) / ratio < 0.25, (name, ratio)  # (a 16 KiB-per-partition sample)
+        # and the stream decodes
+        codec = hc.batch.Codec("Cascaded", hc.CascadedOpts(4096, hc.hipcompType.UINT, *mine))
+        comp = codec.compress(src)
+        dec, actual, statuses = codec.decompress(comp, per * 4)
+        assert statuses.cpu().tolist() == [0] * n and dec.to_host_chunks() == [row.tobytes() for row in col]
+    assert picked["random"] == (0, 0, 0) and picked["small"] == (0, 0, 1), picked
+    assert picked["dimension"][0] >= 1 and picked["sorted"][1] >= 1, picked
+    # an empty batch: the defaults
+    opts, ratio = lib.cascaded_select_opts(0, 0, 0, hc.hipcompType.INT, 0, 0, 0)
+    assert (opts.num_RLEs, opts.num_deltas, opts.use_bp, ratio) == (2, 1, 1, 1.0)

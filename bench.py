@@ -316,7 +316,7 @@ def cpu_codec_baseline(codec: str, sample, reps: int = 2):
 
 def measure_row(hc, lib, codec: str, opts, data, label: dict, key: str, reps: int = 5):
     """One extra row: compress / decompress of `data` through `codec`.  `key` names the row in
-    profiles/r03_rows.json (the rocprof passes of the same workload)."""
+    profiles/rNN_rows.json (the rocprof passes of the same workload)."""
     import torch
     job = CodecJob(hc, lib, codec, opts, data)
     job.compress(); job.decompress(); torch.cuda.synchronize()
@@ -345,6 +345,26 @@ def gen_mixed(n_chunks: int, device):
     a = gen_data("uniform", 0, h, device, 0x5EED0002).view(h, CHUNK)
     b = gen_data("harness", 0, h, device, 0x5EED0003).view(h, CHUNK)
     return torch.stack([a, b], dim=1).reshape(-1).contiguous()
+
+
+def gen_misrouted(kind: str, n_chunks: int, device):
+    """Chunks whose MIDDLE -- the 1 KiB the LZ4 routing kernel looks at (lz4_far.hiph:lz4_route_kernel) --
+    misrepresents them: "text_random_middle" = TPC-H-like text with 1.5 KiB of random bytes in the middle
+    (routed to the LDS shape, made for data without matches, although the chunk compresses);
+    "random_text_middle" = random bytes with 1.5 KiB of text in the middle (routed to the sparse far
+    class although nothing else in the chunk matches).  The bytes never depend on the routing; these rows
+    put a number on what a wrong guess costs."""
+    import torch
+    text = torch.from_numpy(gen_text(n_chunks * CHUNK)).to(device).view(n_chunks, CHUNK)
+    rnd = gen_data("uniform", 0, n_chunks, device, 0x5EED0007).view(torch.uint8).view(n_chunks, CHUNK)
+    lo, hi = 32000, 33536
+    if kind == "text_random_middle":
+        out = text.clone()
+        out[:, lo:hi] = rnd[:, lo:hi]
+    else:
+        out = rnd.clone()
+        out[:, lo:hi] = text[:, lo:hi]
+    return out.reshape(-1).contiguous()
 
 
 def measure_hlif(hc, data, reps: int = 2):
@@ -415,7 +435,7 @@ PROFILED_ROWS = None
 
 
 def profiled(label: str, phase: str):
-    """What the committed rocprofv3 passes say about one bench row's kernel (profiles/r03_rows.json,
+    """What the committed rocprofv3 passes say about one bench row's kernel (profiles/rNN_rows.json,
     written by scripts/collect_profiles.sh + scripts/profile_rows.py): average duration from
     --kernel-trace --stats, HBM-side bytes per launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes
     (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE).  None when
@@ -423,13 +443,14 @@ def profiled(label: str, phase: str):
     records the sha256 of the device sources it was measured on)."""
     global PROFILED_ROWS
     if PROFILED_ROWS is None:
-        path = os.path.join(ROOT, "profiles", "r03_rows.json")
         PROFILED_ROWS = {}
-        if os.path.exists(path):
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_rows.json")), reverse=True):  # (the newest round first)
             with open(path) as f:
                 table = json.load(f)
             if table.get("kernel_source_sha16") == kernel_source_id():
                 PROFILED_ROWS = table.get("rows", {})
+                break
     return PROFILED_ROWS.get(label, {}).get(phase)
 
 
@@ -655,6 +676,14 @@ def main():
                                     {"codec": "LZ4", "distribution": dn if dn != "text" else "tpch_lineitem_text",
                                      "data_type": "CHAR", "note": "a small batch"}, f"lz4/{dn}/char/1000", reps=5))
             del d
+        # what a wrong guess of the routing kernel costs (it looks at 1 KiB from the middle of a chunk)
+        for kind in ("text_random_middle", "random_text_middle"):
+            d = gen_misrouted(kind, 16384, dev)
+            rows.append(measure_row(hc, lib, "LZ4", hc.LZ4Opts(hc.hipcompType.CHAR), d,
+                                    {"codec": "LZ4", "distribution": "misrouted: " + kind, "data_type": "CHAR",
+                                     "note": "the 1.5 KiB around the routing sample misrepresent the chunk"},
+                                    f"lz4/misrouted_{kind}/char/16384", reps=3))
+            del d
         tchunks = args.text_chunks
         text_host = gen_text(tchunks * CHUNK)
         text = torch.from_numpy(text_host).to(dev)
@@ -674,7 +703,24 @@ def main():
         if not args.no_cpu:
             crow["cpu_baseline"] = cpu_codec_baseline("Cascaded", cols[: 8192 * CHUNK].cpu().numpy())
         rows.append(crow)
-        del cols
+        # the option selector (include/hipcomp/cascaded_select.h, an API of this library's own): what it picks
+        # for the config-3 columns and for a column that should not be cascaded at all, and the ratio that buys
+        for cname, cdata in (("sorted", cols), ("uniform", gen_data("uniform", 0, 16384, dev, seeds["uniform"]).view(torch.uint8))):
+            job = CodecJob(hc, lib, "Cascaded", hc.CascadedOpts(4096, hc.hipcompType.UINT, 2, 1, 1), cdata)
+            temp = torch.empty(lib.cascaded_select_temp_size(), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            opts, est = lib.cascaded_select_opts(job.src.ptrs.data_ptr(), job.src.sizes.data_ptr(), job.n, hc.hipcompType.UINT,
+                                                 temp.data_ptr(), temp.numel(), torch.cuda.current_stream().cuda_stream)
+            select_ms = (time.perf_counter() - t0) * 1e3
+            del job, temp
+            srow2 = measure_row(hc, lib, "Cascaded", hc.CascadedOpts(4096, hc.hipcompType.UINT, opts.num_RLEs, opts.num_deltas, opts.use_bp),
+                                cdata, {"codec": "Cascaded", "config": f"options picked by hipcompBatchedCascadedSelectOpts for the {cname} columns",
+                                        "selected_opts": {"num_RLEs": opts.num_RLEs, "num_deltas": opts.num_deltas, "use_bp": opts.use_bp},
+                                        "estimated_ratio": est, "select_ms": select_ms},
+                                f"cascaded/{cname}/selected", reps=3)
+            rows.append(srow2)
+        del cols, cdata
         d = gen_data("uniform", 0, vc, dev, seeds["uniform"]).view(torch.uint8)
         rows.append(measure_hlif(hc, d))
         del d

@@ -11,6 +11,6 @@ for f in glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True
 rows.sort(key=lambda x: -x[2])
 with open(dst, "w") as out:
     out.write("kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n")
-    for r in rows[:12]:
+    for r in rows:
         out.write("%s,%d,%d,%.1f,%.3f,%d,%d\n" % r)
 print(open(dst).read())

@@ -58,6 +58,7 @@
 #include "wave_utils.hpp"
 
 #include <atomic>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -422,6 +423,65 @@ extern "C" int hipcompBatchedLZ4DebugDecodeStamps(unsigned long long* host8, int
 }
 #endif
 
+namespace {
+// ---- the side stream of the prefetch kernel (lz4_mix.hiph) ------------------------------------------
+// One non-blocking stream and two events per device, made on first use and kept.  A call brackets the
+// prefetch kernel with them: the side stream waits for everything the caller's stream holds so far (the
+// header's memset, the routing kernel), the caller's stream waits for the prefetch kernel at the end --
+// so whatever the caller does next, on this stream or after synchronising it, comes after the last read
+// of its arrays.  Nothing here waits on the host.  The record/wait pairs of one call are made under the
+// lock: two host threads share the events, and a wait takes the most recent record.
+// Whatever fails, the call goes on without the companion (it only ever changes speed); a stream that is
+// being captured into a graph goes without as well.
+constexpr int kMostDevices = 64;
+struct PrefetchSide
+{
+  hipStream_t stream = nullptr;
+  hipEvent_t begin = nullptr, end = nullptr;
+  bool tried = false, usable = false;
+};
+std::mutex g_prefetch_lock;
+PrefetchSide g_prefetch_sides[kMostDevices];
+
+// -> the side stream, already waiting for `stream`'s work so far, with the lock HELD; or nullptr
+PrefetchSide* prefetch_side_begin(hipStream_t stream)
+{
+  int device = -1;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMostDevices
+      || hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  g_prefetch_lock.lock();
+  PrefetchSide& side = g_prefetch_sides[device];
+  if (!side.tried) {
+    side.tried = true;
+    side.usable = hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking) == hipSuccess
+                  && hipEventCreateWithFlags(&side.begin, hipEventDisableTiming) == hipSuccess
+                  && hipEventCreateWithFlags(&side.end, hipEventDisableTiming) == hipSuccess;
+  }
+  if (side.usable && hipEventRecord(side.begin, stream) == hipSuccess
+      && hipStreamWaitEvent(side.stream, side.begin, 0) == hipSuccess)
+    return &side;
+  (void)hipGetLastError();
+  g_prefetch_lock.unlock();
+  return nullptr;
+}
+
+void prefetch_side_end(PrefetchSide* side, hipStream_t stream)
+{
+  // (if the record fails the caller's stream cannot be made to wait: wait here, once, rather than let the
+  // prefetch kernel outlive the call)
+  if (hipEventRecord(side->end, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->end, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(side->stream);
+  }
+  g_prefetch_lock.unlock();
+}
+
+} // namespace
+
 size_t lz4_compress_temp_bytes_used(uint32_t ht_size, size_t batch)
 {
   // header, the four class lists, alignment, one table per chunk but no more than the chip holds waves
@@ -477,9 +537,29 @@ hipError_t lz4_launch_compress(
     uint32_t* ticket = header ? header + kClassMix : nullptr;
     // ticket == nullptr: no persistent workgroups, one chunk per wave
     const dim3 grid(ticket ? mix.groups : (unsigned)((batch + mix.waves() - 1) / mix.waves()));
+    const uint32_t per_ticket = chunks_per_ticket((size_t)mix.groups * mix.waves());
+    // the prefetch companion (lz4_mix.hiph): only where the kernel works through a list of whole tickets
+    // that is longer than the chip holds at once
+    PrefetchSide* side = nullptr;
+#ifndef HC_MIX_NO_PREFETCH
+    if (ticket && count && per_ticket == 1 && batch > 2 * (size_t)mix.groups * mix.waves())
+      side = prefetch_side_begin(stream);
+#endif
     mix_kernel_for(elem_size)<<<grid, dim3(mix.waves() * kWave), mix.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
-        (uint32_t)batch, ticket, chunks_per_ticket((size_t)mix.groups * mix.waves()), count, list);
+        (uint32_t)batch, ticket, per_ticket, count, list);
+    if (side) {
+      uint32_t waves = kPrefetchWaves, lead = kPrefetchLead, touch = 1, nap = kPrefetchNap;
+#ifdef HC_MEASUREMENT_KNOBS
+      if (const char* e = std::getenv("HIPCOMP_PREFETCH_WAVES")) waves = (uint32_t)std::atoi(e);
+      if (const char* e = std::getenv("HIPCOMP_PREFETCH_LEAD")) lead = (uint32_t)std::atoi(e);
+      if (const char* e = std::getenv("HIPCOMP_PREFETCH_TOUCH")) touch = (uint32_t)std::atoi(e);
+      if (const char* e = std::getenv("HIPCOMP_PREFETCH_NAP")) nap = (uint32_t)std::atoi(e);
+#endif
+      lz4_prefetch_kernel<<<dim3(waves), dim3(kWave), 0, side->stream>>>(
+          in_ptrs, in_bytes, (uint32_t)batch, ticket, count, list, lead, touch, nap);
+      prefetch_side_end(side, stream);
+    }
   };
   auto launch_far = [&](uint32_t cls, const uint32_t* counts, const uint32_t* all_lists) -> bool {
     const FarGeometry g = far_geometry(ht_size, cls, batch, far_tables ? far_capacity : 0);

@@ -22,7 +22,7 @@ if [ $PART = headline ] || [ $PART = all ]; then
   tail -c 900 $O/${R}_bench_under_rocprof.json.log
 fi
 if [ $PART = rows ] || [ $PART = all ]; then
-  ROWS=${ROWS:-"lz4/uniform/char/100000 lz4/uniform/int/100000 lz4/harness/char/100000 lz4/harness/int/100000 lz4/runs/char/100000 lz4/runs/int/100000 lz4/mixed/char/100000 lz4/text/char/65536 lz4/harness/char/1000 lz4/text/char/1000 snappy/text/65536 cascaded/sorted/100000"}
+  ROWS=${ROWS:-"lz4/uniform/char/100000 lz4/uniform/int/100000 lz4/harness/char/100000 lz4/harness/int/100000 lz4/runs/char/100000 lz4/runs/int/100000 lz4/mixed/char/100000 lz4/misrouted_text_random_middle/char/16384 lz4/misrouted_random_text_middle/char/16384 lz4/text/char/65536 lz4/harness/char/1000 lz4/text/char/1000 snappy/text/65536 cascaded/sorted/100000"}
   PARTNAME=${PARTNAME:-rows}
   SPECS=""
   for ROW in $ROWS; do
@@ -68,5 +68,6 @@ if [ $PART = pmc ] || [ $PART = all ]; then
     echo "-- compress"; python3 scripts/pmc_per_window.py --kernel snappy_compress $U $O/sq1_snappy $O/sq2_snappy;
     echo "-- decompress"; python3 scripts/pmc_per_window.py --kernel snappy_decompress $U $O/sq1_snappy $O/sq2_snappy; } > $O/${R}_snappy_pmc_per_KiB_text.txt
   rm -rf $O/sq1_* $O/sq2_*
+  scripts/pmc_cascaded.sh 100000 $O/casc > $O/${R}_cascaded_pmc_per_subchunk.txt 2>&1 || true
   cat $O/${R}_lz4_pmc_per_window_uniform_char.txt $O/${R}_lz4_pmc_per_sequence_*.txt $O/${R}_snappy_pmc_per_KiB_text.txt
 fi

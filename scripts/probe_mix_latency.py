@@ -1,0 +1,25 @@
+"""Timing probe for the headline kernel: is it waiting for HBM?  The same batch with every input pointer
+aimed at chunk 0 (64 KiB that stay in L2): what the kernel computes per chunk is the same, what it
+waits for is not.  probe_mix_latency.py [--chunks N]"""
+import argparse, importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+ap = argparse.ArgumentParser()
+ap.add_argument("--chunks", type=int, default=100000)
+a = ap.parse_args()
+hc = importlib.import_module("hipcomp-core_amd")
+dev = torch.device("cuda:0")
+data = bench.gen_data("uniform", 0, a.chunks, dev, 0x5EED0002)
+for dt, name in ((hc.hipcompType.CHAR, "char"), (hc.hipcompType.INT, "int")):
+    job = bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(dt), data)
+    job.compress(); torch.cuda.synchronize()
+    tc, _ = bench.time_phases(job, 5)
+    base = min(tc)
+    for k in (1, 256, 4096):
+        job.src.ptrs[:] = job.src.ptrs[:k].repeat((a.chunks + k - 1) // k)[: a.chunks]   # inputs: k distinct chunks only
+        job.compress(); torch.cuda.synchronize()
+        tc2, _ = bench.time_phases(job, 5)
+        print(f"uniform {name} n={a.chunks}: compress {base:.3f} ms ({job.total / base / 1e6:.1f} GB/s); all inputs from {k} chunk(s) ({k * 64} KiB): {min(tc2):.3f} ms ({job.total / min(tc2) / 1e6:.1f} GB/s)", flush=True)
+    del job

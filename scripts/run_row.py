@@ -22,6 +22,8 @@ if codec == "lz4":
         data = torch.from_numpy(bench.gen_text(n * bench.CHUNK)).to(dev)
     elif dist == "mixed":
         data = bench.gen_mixed(n, dev)
+    elif dist.startswith("misrouted_"):
+        data = bench.gen_misrouted(dist[len("misrouted_"):], n, dev)
     else:
         data = bench.gen_data(dist, 0, n, dev, seeds[dist])
     job = bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(hc.hipcompType.CHAR if dt == "char" else hc.hipcompType.INT), data)

@@ -37,6 +37,8 @@ for row in a.rows:
             data = text_of(n)
         elif dist == "mixed":
             data = bench.gen_mixed(n, dev)
+        elif dist.startswith("misrouted_"):
+            data = bench.gen_misrouted(dist[len("misrouted_"):], n, dev)
         else:
             data = bench.gen_data(dist, 0, n, dev, seeds[dist])
         job = bench.CodecJob(hc, lib, "LZ4", hc.LZ4Opts(hc.hipcompType.CHAR if dt == "char" else hc.hipcompType.INT), data)

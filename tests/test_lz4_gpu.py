@@ -647,3 +647,50 @@ def test_match_at_lane_63_with_the_next_window_beyond_it(hc, oracle, reflib, cud
             assert got[i] == want[i], f"chunk {i} {tname} shape={lz4_shape}: kernel != oracle"
         _round_trip(hc, mine, chunks, dtype)
     compare_with_reference(reflib, "lane 63", _reference_agrees(hc, cases, dtype, 65536, [_want(oracle, c, es, 65536) for c in cases], tname))
+
+
+def test_two_host_threads_on_two_streams_share_the_prefetch_side_stream(hc, cuda):
+    """The mix kernel's prefetch companion runs on one side stream per device, bracketed by two shared events
+    (lz4_kernels.hip, prefetch_side_begin/_end): two host threads compressing on two streams at once must each
+    get the bytes a lone call gets, and every call's arrays must be free to reuse once its own stream is
+    synchronised."""
+    import threading
+    import torch
+    import bench
+    n = 6000   # (more than twice what the chip holds at once: the companion is launched)
+    data = [bench.gen_data("uniform", 0, n, cuda, 0x5EED0100 + i) for i in range(2)]
+    jobs = [bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(hc.hipcompType.CHAR), d) for d in data]
+    alone = []
+    for job in jobs:
+        job.compress()
+        torch.cuda.synchronize()
+        alone.append((job.comp.sizes.clone(), job.comp.data.clone()))
+    streams = [torch.cuda.Stream(device=cuda) for _ in jobs]
+    errors = []
+
+    def run(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(6):
+                    jobs[i].comp.data.zero_()
+                    jobs[i].compress()
+                jobs[i].decompress()
+            streams[i].synchronize()
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for job, (sizes, comp) in zip(jobs, alone):
+        assert torch.equal(job.comp.sizes, sizes)
+        stride = job.comp.stride
+        A = job.comp.data[: n * stride].view(n, stride)
+        B = comp[: n * stride].view(n, stride)
+        idx = torch.arange(stride, device=cuda)[None, :] < sizes[:, None]
+        assert bool(((A == B) | ~idx).all().item())
+        job.verify()

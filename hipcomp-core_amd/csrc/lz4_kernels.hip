@@ -549,15 +549,20 @@ hipError_t lz4_launch_compress(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
         (uint32_t)batch, ticket, per_ticket, count, list);
     if (side) {
-      uint32_t waves = kPrefetchWaves, lead = kPrefetchLead, touch = 1, nap = kPrefetchNap;
+      uint32_t waves = kPrefetchWaves, lead = kPrefetchLead, behind = kPrefetchBehind, nap = kPrefetchNap;
+      uint32_t* trace = nullptr;
+      uint32_t trace_words = 0;
 #ifdef HC_MEASUREMENT_KNOBS
       if (const char* e = std::getenv("HIPCOMP_PREFETCH_WAVES")) waves = (uint32_t)std::atoi(e);
       if (const char* e = std::getenv("HIPCOMP_PREFETCH_LEAD")) lead = (uint32_t)std::atoi(e);
-      if (const char* e = std::getenv("HIPCOMP_PREFETCH_TOUCH")) touch = (uint32_t)std::atoi(e);
+      if (const char* e = std::getenv("HIPCOMP_PREFETCH_BEHIND")) behind = (uint32_t)std::atoi(e);
       if (const char* e = std::getenv("HIPCOMP_PREFETCH_NAP")) nap = (uint32_t)std::atoi(e);
+      // (the ticket counter over time, into the dense class's list -- empty on the data this is used with)
+      if (std::getenv("HIPCOMP_PREFETCH_TRACE") && lists) { trace = lists + kClassDense * batch; trace_words = (uint32_t)batch; }
 #endif
-      lz4_prefetch_kernel<<<dim3(waves), dim3(kWave), 0, side->stream>>>(
-          in_ptrs, in_bytes, (uint32_t)batch, ticket, count, list, lead, touch, nap);
+      // (one wave more: the one that watches the ticket counter for the others)
+      lz4_prefetch_kernel<<<dim3(waves + 1u), dim3(kWave), 0, side->stream>>>(
+          in_ptrs, in_bytes, (uint32_t)batch, ticket, header + kHeaderPublished, count, list, lead, behind, nap, trace, trace_words);
       prefetch_side_end(side, stream);
     }
   };

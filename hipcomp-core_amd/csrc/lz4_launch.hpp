@@ -41,9 +41,9 @@ enum class Lz4Mode { Auto, Mix, Far, FarSparse, FarWide };
 Lz4Mode lz4_mode_from_environment();
 
 // `temp` / `temp_bytes`: the caller's temp buffer (hipcompBatchedLZ4CompressGetTempSize bytes by
-// contract), used while the call runs as far as it goes: 16 words of header -- a chunk ticket
-// counter and a list length per launch shape, sample totals -- zeroed by the launcher on the
-// stream, the routing kernel's lists (4 x batch words), and hash tables for the far kernel's
+// contract), used while the call runs as far as it goes: 64 words of header -- a chunk ticket
+// counter and a list length per launch shape, sample totals, the word of the prefetch kernel's first
+// wave (lz4_far.hiph, kHeaderWords) -- zeroed by the launcher on the stream, the routing kernel's lists (4 x batch words), and hash tables for the far kernel's
 // device-table waves (max(ht_size, 8) uint16 each, 16-byte aligned).  Too small for the lists:
 // no routing, the LDS shape for all; too small for the header: one chunk per wave.  nullptr / 0
 // is accepted (the same).  batch must be > 0 and < 2^31.

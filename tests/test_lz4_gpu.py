@@ -31,7 +31,7 @@ def _want(oracle, c: bytes, es: int, max_chunk: int, **kw) -> bytes:
 
 
 def _header(temp):
-    """the launcher's 16-word header at the head of the temp buffer (lz4_launch.hpp): ticket counters
+    """the launcher's 64-word header at the head of the temp buffer (lz4_launch.hpp): ticket counters
     and list lengths per class {mix, dense, sparse, wide}, totals of the samples"""
     import torch
     h = temp[:64].view(torch.int32).cpu().tolist()
@@ -148,7 +148,7 @@ def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, lz4_s
         forced = {"mix": 0, "far": 1, "fars": 2, "farw": 3}[lz4_shape]
         assert tickets[forced] >= src.n and sum(counts) == 0
     if lz4_shape in ("far", "fars", "farw"):                           # 1536 chunks: device-table waves beside the LDS ones
-        assert bool((temp[64 + 16 * src.n:] != 0xAB).any().item())     # hash tables in the temp buffer were written
+        assert bool((temp[256 + 16 * src.n:] != 0xAB).any().item())     # hash tables in the temp buffer were written
     got = dst.to_host_chunks()
     for i in range(len(chunks)):
         assert got[i] == want[i % 48], f"chunk {i} {tname} shape={lz4_shape}: kernel != oracle"

@@ -255,6 +255,13 @@ struct Core
   uint8_t* scratch = nullptr;
   bool own_scratch = false;
   CommonHeader* header_host = nullptr; // pinned
+  // compress: the placing + gathering of slab i runs on a stream of the manager's own beside the
+  // compression of slab i + 1 (two sets of slots).  The encoders are bound by latency, the gather by
+  // HBM: side by side they cost little more than the encoders alone.  Events: slots[b] filled /
+  // slots[b] free again.  Made on first use; if that fails, everything runs on the one stream.
+  hipStream_t side = nullptr;
+  hipEvent_t filled[2] = {nullptr, nullptr}, emptied[2] = {nullptr, nullptr};
+  bool side_tried = false;
 
   Core(Codec c, size_t chunk, hipStream_t st, int device_id, const char* who) : codec(c), chunk_bytes(chunk), stream(st)
   {
@@ -269,6 +276,37 @@ struct Core
     if (own_scratch)
       (void)hipFree(scratch);
     (void)hipHostFree(header_host);
+    for (int b = 0; b < 2; ++b) {
+      if (filled[b])
+        (void)hipEventDestroy(filled[b]);
+      if (emptied[b])
+        (void)hipEventDestroy(emptied[b]);
+    }
+    if (side)
+      (void)hipStreamDestroy(side);
+  }
+  // the side stream, or nullptr (not available, or `stream` is being captured into a graph)
+  hipStream_t side_stream()
+  {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    if (!side_tried) {
+      side_tried = true;
+      bool ok = hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess;
+      for (int b = 0; b < 2 && ok; ++b)
+        ok = hipEventCreateWithFlags(&filled[b], hipEventDisableTiming) == hipSuccess
+             && hipEventCreateWithFlags(&emptied[b], hipEventDisableTiming) == hipSuccess;
+      if (!ok) {
+        (void)hipGetLastError();
+        if (side)
+          (void)hipStreamDestroy(side);
+        side = nullptr;
+      }
+    }
+    return side;
   }
   Core(const Core&) = delete;
   Core& operator=(const Core&) = delete;
@@ -288,13 +326,30 @@ struct Core
   // scratch: chunk lists of a slab, the slots, and (LZ4) the compress launcher's own temp space
   // (its header, routing lists and hash tables for a slab: lz4_launch.hpp)
   size_t lists_bytes() const { return (size_t)slab * (8 + 8 + 8 + 8 + 8 + 4) + 64; }
-  size_t lz4_temp_bytes() const { return codec == LZ4 ? lz4_compress_temp_bytes_used(ht_size, slab) : 0; }
-  size_t scratch_bytes() const { return lists_bytes() + (size_t)slab * slot_bytes + 16 + lz4_temp_bytes(); }
-  uint8_t* ensure_scratch()
+  size_t lz4_temp_bytes(size_t chunks) const { return codec == LZ4 ? lz4_compress_temp_bytes_used(ht_size, chunks) : 0; }
+  // `sets` sets of slots for `chunks` chunks each
+  size_t scratch_bytes_for(size_t chunks, int sets) const
   {
-    if (!scratch) {
-      check(hipMalloc((void**)&scratch, scratch_bytes()), "hipMalloc(scratch)");
+    return lists_bytes() + (size_t)sets * chunks * slot_bytes + 16 + lz4_temp_bytes(chunks);
+  }
+  // what a caller's own scratch buffer must hold: two slabs (compress overlaps the placing of one
+  // with the compression of the next)
+  size_t scratch_bytes() const { return scratch_bytes_for(slab, 2); }
+  // The manager's own scratch is as large as the calls so far needed (a buffer of a few chunks does not
+  // pay for two slabs of 2 GiB); the caller's is scratch_bytes() by contract.
+  size_t own_capacity = 0;
+  uint8_t* ensure_scratch(size_t need)
+  {
+    if (scratch && !own_scratch)
+      return scratch;
+    if (!scratch || own_capacity < need) {
+      if (scratch)
+        (void)hipFree(scratch); // (waits for whatever still uses it)
+      scratch = nullptr;
+      own_capacity = 0;
+      check(hipMalloc((void**)&scratch, need), "hipMalloc(scratch)");
       own_scratch = true;
+      own_capacity = need;
     }
     return scratch;
   }
@@ -311,19 +366,28 @@ struct Core
   {
     if (reinterpret_cast<uintptr_t>(comp_buffer) & 7)
       throw std::runtime_error("compress: the container buffer must be 8-byte aligned");
-    uint8_t* const s = ensure_scratch();
     const size_t n = cfg.num_chunks;
+    // (one slab: nothing to overlap, one set of slots)
+    hipStream_t const placing = n > slab ? side_stream() : nullptr;
+    const size_t per_set = n < slab ? (n ? n : 1) : slab;
+    uint8_t* const s = ensure_scratch(scratch_bytes_for(per_set, placing ? 2 : 1));
     const Layout lay = layout(n);
     const uint8_t** in_ptrs = reinterpret_cast<const uint8_t**>(s);
     size_t* in_bytes = reinterpret_cast<size_t*>(s + (size_t)slab * 8);
     uint8_t** out_ptrs = reinterpret_cast<uint8_t**>(s + (size_t)slab * 16);
-    uint8_t* slots = s + lists_bytes();
+    uint8_t* const slots0 = s + lists_bytes();
     uint8_t* lz4_temp = reinterpret_cast<uint8_t*>(
-        (reinterpret_cast<uintptr_t>(slots + (size_t)slab * slot_bytes) + 15) & ~uintptr_t(15));
+        (reinterpret_cast<uintptr_t>(slots0 + (placing ? 2 : 1) * per_set * slot_bytes) + 15) & ~uintptr_t(15));
     header_kernel<<<1, 1, 0, stream>>>(comp_buffer, cfg.uncompressed_buffer_size, n, chunk_bytes, (uint32_t)lay.data,
                                        format, format_header, format_header_bytes, cfg.get_status());
-    for (size_t first = 0; first < n; first += slab) {
+    bool used[2] = {false, false};
+    size_t pass = 0;
+    for (size_t first = 0; first < n; first += slab, ++pass) {
       const uint32_t count = (uint32_t)(n - first < slab ? n - first : slab);
+      const int b = placing ? (int)(pass & 1) : 0;
+      uint8_t* const slots = slots0 + (size_t)b * per_set * slot_bytes;
+      if (placing && used[b]) // (the gather of two slabs ago has emptied these slots)
+        check(hipStreamWaitEvent(stream, emptied[b], 0), "compress: wait for the slots");
       slab_inputs_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, stream>>>(
           decomp_buffer, cfg.uncompressed_buffer_size, chunk_bytes, first, count, slots, slot_bytes, in_ptrs, in_bytes,
           out_ptrs);
@@ -331,7 +395,7 @@ struct Core
       size_t* sizes = reinterpret_cast<size_t*>(comp_buffer + lay.sizes) + first;
       switch (codec) {
       case LZ4:
-        check(lz4_launch_compress(in_ptrs, in_bytes, out_ptrs, sizes, ht_size, count, lz4_elem, lz4_temp, lz4_temp_bytes(),
+        check(lz4_launch_compress(in_ptrs, in_bytes, out_ptrs, sizes, ht_size, count, lz4_elem, lz4_temp, lz4_temp_bytes(per_set),
                                   chunk_bytes, lz4_mode_from_environment(), stream),
               "LZ4Manager::compress");
         break;
@@ -350,10 +414,25 @@ struct Core
           throw std::runtime_error("CascadedManager::compress: batched compress failed");
         break;
       }
-      slab_place_kernel<<<1, kBlock, 0, stream>>>(comp_buffer, lay.sizes, lay.offsets, first, count, place_align);
-      slab_gather_kernel<<<(count + 3) / 4, kBlock, 0, stream>>>(comp_buffer, lay.sizes, lay.offsets, lay.data, first,
-                                                                 count, slots, slot_bytes);
+      hipStream_t const where = placing ? placing : stream;
+      if (placing) {
+        check(hipEventRecord(filled[b], stream), "compress: slots filled");
+        check(hipStreamWaitEvent(placing, filled[b], 0), "compress: wait for the slab");
+      }
+      // (the running total of the container lives in its header: the placing of the slabs is in order
+      // because it is all on one stream)
+      slab_place_kernel<<<1, kBlock, 0, where>>>(comp_buffer, lay.sizes, lay.offsets, first, count, place_align);
+      slab_gather_kernel<<<(count + 3) / 4, kBlock, 0, where>>>(comp_buffer, lay.sizes, lay.offsets, lay.data, first,
+                                                                count, slots, slot_bytes);
+      if (placing) {
+        check(hipEventRecord(emptied[b], placing), "compress: slots emptied");
+        used[b] = true;
+      }
     }
+    // the caller's stream goes on when the container is whole
+    for (int b = 0; b < 2; ++b)
+      if (placing && used[b])
+        check(hipStreamWaitEvent(stream, emptied[b], 0), "compress: wait for the container");
     check(hipGetLastError(), "compress kernels");
   }
 
@@ -395,7 +474,7 @@ struct Core
 
   void decompress(uint8_t* decomp_buffer, const uint8_t* comp_buffer, const hipcomp::DecompressionConfig& cfg)
   {
-    uint8_t* const s = ensure_scratch();
+    uint8_t* const s = ensure_scratch(lists_bytes());
     const size_t n = cfg.num_chunks;
     const Layout lay = layout(n);
     const uint8_t** comp_ptrs = reinterpret_cast<const uint8_t**>(s);
@@ -442,6 +521,7 @@ struct Core
     if (own_scratch)
       (void)hipFree(scratch);
     own_scratch = false;
+    own_capacity = 0;
     scratch = new_scratch_buffer;
   }
 

@@ -471,14 +471,18 @@ __device__ __forceinline__ void load16_global(cgptr src, uint32_t n, uint32_t (&
 {
   // (one per-lane offset, the steps as immediate offsets of the loads; the lanes behind n in the last
   // step read element n - 1 again: in bounds, and not used by anything)
-  const HC_GLOBAL uint32_t* p = reinterpret_cast<const HC_GLOBAL uint32_t*>(src) + lane;
+  // (the base is wave-uniform -- scalar registers -- and the lane's offset one 32-bit register for all 16
+  // loads, the steps their immediate offsets: sixteen 64-bit addresses kept across the loop over the
+  // sub-chunks were being spilled, and every reload of one waits for the stores of the sub-chunk before)
+  const HC_GLOBAL uint32_t* base = reinterpret_cast<const HC_GLOBAL uint32_t*>(src);
+  const uint32_t at = (uint32_t)lane;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     v[k] = 0;
     if (64u * k + 64u <= n) // (wave-uniform)
-      v[k] = p[64 * k];
+      v[k] = base[at + 64u * k];
     else if (64u * k < n)
-      v[k] = reinterpret_cast<const HC_GLOBAL uint32_t*>(src)[min(64u * k + (uint32_t)lane, n - 1u)];
+      v[k] = base[min(64u * k + at, n - 1u)];
   }
 }
 __device__ __forceinline__ void load16_lds(const uint8_t* X, uint32_t n, uint32_t (&v)[16], int lane)
@@ -573,33 +577,89 @@ __device__ __forceinline__ uint32_t rle16(const uint32_t (&v)[16], uint32_t n, u
   return m;
 }
 
-// y[0 .. 32) of BW bits each -> BW words, LSB first (reference block_bitpack :523-552), all shifts
-// known at compile time: one v_lshl_or_b32 per element, a second instruction where an element
-// straddles two words.  The words go to data[w0 .. w0 + BW): all of them at once from a lane whose
-// block lies wholly inside the array (`whole`), else word by word up to `words`, the array's last
-// word without the bits of the fill behind its last element (`last_mask`).
-template <int BW, class Get>
-__device__ __forceinline__ void pack32_store(
-    Get get, HC_GLOBAL uint32_t* data, uint32_t w0, uint32_t mine, uint32_t last_at, uint32_t last_mask)
+#define HC_LDS __attribute__((address_space(3)))
+
+// Bit packing, 16 elements per lane (reference block_bitpack :523-552: element i at bit i BW, LSB first).
+// A PAIR of lanes makes the BW words of 32 elements: the even lane packs elements [0, 16) from bit 0 on,
+// the odd lane [16, 32) -- also from bit 0 on, and where BW is odd its 16 BW bits start in the middle of a
+// word: the even lane then takes the odd lane's first half word into the upper half of its last one (one
+// DPP move), and the odd lane's words are its own moved down by 16 bits (one v_alignbit each).  All shifts
+// are known at compile time: one v_lshl_or_b32 per item, a second instruction where an item straddles two
+// words.  PAIRS: the items are pairs of elements already joined to 2 BW bits (the run lengths, which
+// come two to a register).  (Round 4, second pass: 32 elements per lane left 40 of the 64 lanes idle on
+// arrays of 700 - 800 elements -- a sub-chunk of a sorted column -- at the full instruction count.)
+template <int BW, bool PAIRS, class Get>
+__device__ __forceinline__ void pack16_store(
+    Get get, HC_GLOBAL uint32_t* data, uint32_t words, uint32_t last_mask, int lane)
 {
-  uint32_t w[BW];
+  constexpr int EB = PAIRS ? 2 * BW : BW, NI = PAIRS ? 8 : 16;
+  constexpr int H = (BW + 1) / 2; // words of 16 elements from bit 0 on = the words an even lane writes
+  uint32_t w[H];
 #pragma unroll
-  for (int j = 0; j < BW; ++j)
+  for (int j = 0; j < H; ++j)
     w[j] = 0;
 #pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    const int p = k * BW, word = p >> 5, sh = p & 31;
-    const uint32_t yk = get(k);
-    w[word % BW] |= yk << sh;
-    if (sh + BW > 32)
-      w[(word + 1) % BW] |= yk >> (32 - sh);
+  for (int i = 0; i < NI; ++i) {
+    const int p = i * EB, word = p >> 5, sh = p & 31;
+    const uint32_t item = get(i);
+    w[word] |= item << sh;
+    if (sh + EB > 32)
+      w[word + 1] |= item >> (32 - sh);
   }
-  // `mine` of my BW words lie inside the array; word `last_at` of mine (if it is one of them) is the
-  // array's last and loses the bits of the fill behind its last element
+  // (the lane number through an empty asm statement: what depends on it below -- for each of the 33 bit
+  // widths -- is then not something to compute once in front of the loop over the sub-chunks, keep in 60
+  // registers and spill; a reload from scratch waits for every store before it)
+  asm volatile("" : "+v"(lane));
+  const bool odd = (lane & 1) != 0;
+  uint32_t mine = (uint32_t)H;
+  if constexpr ((BW & 1) != 0) {
+    // (quad_perm [1, 1, 3, 3]: every lane reads the odd lane of its pair)
+    const uint32_t first_of_odd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0], 0xF5, 0xF, 0xF, false);
+    const uint32_t shared = w[H - 1] | (first_of_odd << 16);
 #pragma unroll
-  for (int j = 0; j < BW; ++j)
-    if ((uint32_t)j < mine)
-      data[w0 + j] = (uint32_t)j == last_at ? w[j] & last_mask : w[j];
+    for (int j = 0; j + 1 < H; ++j) {
+      const uint32_t down = __builtin_amdgcn_alignbit(w[j + 1], w[j], 16);
+      w[j] = odd ? down : w[j];
+    }
+    w[H - 1] = shared;
+    mine = odd ? (uint32_t)(H - 1) : (uint32_t)H;
+  }
+  // my words: the pair's are [pair BW, pair BW + BW), the odd lane's behind the even lane's H; the array's
+  // last word holds no bit of the fill behind its last element
+  const uint32_t w0 = (uint32_t)(lane >> 1) * (uint32_t)BW + (odd ? (uint32_t)H : 0u);
+  const uint32_t inside = min(words - min(w0, words), mine); // how many of my words lie inside the array
+  const uint32_t last_at = words - 1u - w0;                  // (which of mine is the array's last word, if any)
+  HC_GLOBAL uint32_t* const q = data + w0;
+#pragma unroll
+  for (int j = 0; j < H; ++j)
+    if ((uint32_t)j < inside)
+      q[j] = (uint32_t)j == last_at ? w[j] & last_mask : w[j];
+}
+
+// 4-byte values of 17 .. 31 bits (columns that hardly compress): 32 elements per lane, the shifts in
+// scalar registers, a loop that is not unrolled: the element goes from LDS into the accumulator and is gone.
+__device__ __forceinline__ void write_wide4(
+    HC_GLOBAL uint32_t* data, const HC_LDS uint8_t* X, uint32_t n, uint32_t bw, uint32_t fr, uint32_t words,
+    uint32_t last_mask, int lane)
+{
+  const uint32_t blocks = (n + 31u) >> 5;
+  if ((uint32_t)lane >= blocks)
+    return;
+  const HC_LDS uint8_t* p = X + (uint32_t)lane * 132u;
+  uint64_t acc = 0;
+  uint32_t sh = 0, wi = (uint32_t)lane * bw;
+#pragma nounroll
+  for (int k = 0; k < 32; ++k) {
+    acc |= (uint64_t)(*reinterpret_cast<const HC_LDS uint32_t*>(p + 4 * k) - fr) << sh;
+    sh += bw;
+    if (sh >= 32u) { // (wave-uniform; once per element at these widths)
+      if (wi < words)
+        data[wi] = wi + 1u == words ? (uint32_t)acc & last_mask : (uint32_t)acc;
+      ++wi;
+      acc >>= 32;
+      sh -= 32u;
+    }
+  }
 }
 
 // One array of the sub-chunk to HBM (reference block_write :646-680 / get_for_bitwidth :394-471 /
@@ -612,41 +672,40 @@ __device__ __forceinline__ uint32_t write_array4(
     gptr out, uint32_t off, uint32_t limit, const uint8_t* X, const uint8_t* Eb, uint32_t n, int bp, int lane)
 {
   constexpr uint32_t ES = LENGTHS ? 2 : 4;
+  typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
   HC_GLOBAL uint32_t* dst = reinterpret_cast<HC_GLOBAL uint32_t*>(out + off);
-  // my 32 elements: block min(lane, last block) -- the lanes behind the array look at its last
-  // block again, which moves neither minimum nor maximum, and store nothing
-  const uint32_t blocks = (n + 31u) >> 5;
+  // my 16 elements: block min(lane, last block) -- the lanes behind the array look at its last
+  // block again, which moves neither minimum nor maximum, and what they pack is stored nowhere
+  const uint32_t blocks = (n + 15u) >> 4;
   const uint32_t tb = blocks == 0 ? 0u : min((uint32_t)lane, blocks - 1u);
-  uint32_t y[32];
+  uint32_t y[16];
   uint32_t bw = 8 * ES; // (a raw array is its elements at their full width, no frame of reference)
   uint32_t fr = 0;
   if (LENGTHS) {
     // run lengths = differences of the run ends, two at a time (16-bit halves): pair q = {end 2q, end 2q + 1}
     // minus {end 2q - 1, end 2q}
-    const uint8_t* p = Eb + tb * 68u;
-    uint32_t e[16], len2[16];
+    const uint8_t* p = Eb + (tb * 32u + (tb >> 1) * 4u); // e4_addr(16 tb)
+    uint32_t e[8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
+    for (int q = 0; q < 8; ++q)
       e[q] = *reinterpret_cast<const uint32_t*>(p + 4 * q);
-    // the run end in front of my block: the last one of the block below (block 0: 0); its entry
-    // lies at - 6 (the dword at - 4 is padding)
-    uint32_t below = tb == 0 ? 0u : (uint32_t)*reinterpret_cast<const uint16_t*>(p - 6) << 16;
+    // the run end in front of my block: the entry below (block 0: 0) -- for an even block behind the
+    // dword of padding
+    uint32_t below = tb == 0 ? 0u : (uint32_t)*reinterpret_cast<const uint16_t*>(p - ((tb & 1u) ? 2 : 6)) << 16;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < 8; ++q) {
       const uint32_t shifted = __builtin_amdgcn_alignbit(e[q], below, 16); // {hi of the pair below, my lo}
-      typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
       const u16x2 d = __builtin_bit_cast(u16x2, e[q]) - __builtin_bit_cast(u16x2, shifted);
-      len2[q] = __builtin_bit_cast(uint32_t, d);
       below = e[q];
+      y[q] = __builtin_bit_cast(uint32_t, d);
     }
     if (bp) {
       // frame of reference = the smallest length, bit width from largest - smallest (reference
       // get_for_bitwidth :394-471; lengths are 1 .. 1024: the same signed or not)
-      typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-      u16x2 mn2 = __builtin_bit_cast(u16x2, len2[0]), mx2 = mn2;
+      u16x2 mn2 = __builtin_bit_cast(u16x2, y[0]), mx2 = mn2;
 #pragma unroll
-      for (int q = 1; q < 16; ++q) {
-        const u16x2 x = __builtin_bit_cast(u16x2, len2[q]);
+      for (int q = 1; q < 8; ++q) {
+        const u16x2 x = __builtin_bit_cast(u16x2, y[q]);
         mn2 = __builtin_elementwise_min(mn2, x);
         mx2 = __builtin_elementwise_max(mx2, x);
       }
@@ -660,16 +719,13 @@ __device__ __forceinline__ uint32_t write_array4(
       fr = (uint32_t)mn;
       const uint32_t fr2 = fr | (fr << 16);
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        len2[q] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, len2[q]) - __builtin_bit_cast(u16x2, fr2));
+      for (int q = 0; q < 8; ++q)
+        y[q] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, y[q]) - __builtin_bit_cast(u16x2, fr2));
     }
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-      y[q] = len2[q]; // (two lengths per register)
   } else {
-    const uint8_t* p = X + tb * 132u;
+    const uint8_t* p = X + (tb * 16u + (tb >> 1)) * 4u; // x4_addr(16 tb)
 #pragma unroll
-    for (int k = 0; k < 32; ++k)
+    for (int k = 0; k < 16; ++k)
       y[k] = *reinterpret_cast<const uint32_t*>(p + 4 * k);
     if (bp) {
       // frame of reference = minimum under the SIGNED interpretation, bit width from max - min
@@ -678,7 +734,7 @@ __device__ __forceinline__ uint32_t write_array4(
         mn = (int32_t)y[0];
         mx = mn;
 #pragma unroll
-        for (int k = 1; k < 32; ++k) {
+        for (int k = 1; k < 16; ++k) {
           const int32_t x = (int32_t)y[k];
           mn = x < mn ? x : mn;
           mx = x > mx ? x : mx;
@@ -689,9 +745,11 @@ __device__ __forceinline__ uint32_t write_array4(
       const uint32_t range = (uint32_t)mx - (uint32_t)mn;
       bw = range ? 32u - (uint32_t)__builtin_clz(range) : 0u;
       fr = (uint32_t)mn;
+      if (bw <= 16u || bw == 32u) { // (the wide path reads the array again)
 #pragma unroll
-      for (int k = 0; k < 32; ++k)
-        y[k] -= fr;
+        for (int k = 0; k < 16; ++k)
+          y[k] -= fr;
+      }
     }
   }
   const uint32_t bits = n * bw;
@@ -704,39 +762,39 @@ __device__ __forceinline__ uint32_t write_array4(
     dst[0] = LENGTHS ? (fr & 0xFFFFu) : fr;
     dst[1] = (bw << 16) | n;
   }
-  if (words == 0 || (uint32_t)lane >= blocks)
+  if (words == 0)
     return ob;
   HC_GLOBAL uint32_t* data = dst + (bp ? 2 : 0);
-  // my words: [lane bw, lane bw + bw) of the array; the last word of the array holds no bit of the fill
   const uint32_t tail = bits & 31u;
   const uint32_t last_mask = tail ? (1u << tail) - 1u : ~0u;
-  const uint32_t w0 = (uint32_t)lane * bw;
-  const uint32_t mine = min(words - min(w0, words), bw); // how many of my bw words lie inside the array
-  const uint32_t last_at = words - 1u - w0;              // (which of mine is the array's last word, if any)
-  auto get = [&](int k) -> uint32_t { return LENGTHS ? (y[(k / 2) % 32] >> (16 * (k & 1))) & 0xFFFFu : y[k % 32]; };
-  switch (bw) {
-#define HC_CASE(B) case B: pack32_store<B>(get, data, w0, mine, last_at, last_mask); break;
-    HC_CASE(1) HC_CASE(2) HC_CASE(3) HC_CASE(4) HC_CASE(5) HC_CASE(6) HC_CASE(7) HC_CASE(8)
-    HC_CASE(9) HC_CASE(10) HC_CASE(11) HC_CASE(12) HC_CASE(13) HC_CASE(14) HC_CASE(15) HC_CASE(16)
-    HC_CASE(32)
-#undef HC_CASE
-  default: {
-    // the bit widths 17 .. 31 (columns that hardly compress): the same with the shifts in scalar registers
-    uint64_t acc = 0;
-    uint32_t sh = 0, wi = w0;
+  if (LENGTHS) {
+    // two lengths of a register -> one item of 2 bw bits: lo | hi << bw (both below 2^bw)
+    if (bw < 16u) {
+      const uint32_t low = (1u << bw) - 1u;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      acc |= (uint64_t)get(k) << sh;
-      sh += bw;
-      if (sh >= 32u) { // (wave-uniform; once per element at these widths)
-        if (wi < words)
-          data[wi] = wi + 1u == words ? (uint32_t)acc & last_mask : (uint32_t)acc;
-        ++wi;
-        acc >>= 32;
-        sh -= 32u;
-      }
+      for (int q = 0; q < 8; ++q)
+        y[q] = (y[q] & low) | ((y[q] >> (16u - bw)) & ~low);
     }
-  } break;
+    auto get = [&](int i) -> uint32_t { return y[i % 8]; };
+    switch (bw) {
+#define HC_CASE(B) case B: pack16_store<B, true>(get, data, words, last_mask, lane); break;
+      HC_CASE(1) HC_CASE(2) HC_CASE(3) HC_CASE(4) HC_CASE(5) HC_CASE(6) HC_CASE(7) HC_CASE(8)
+      HC_CASE(9) HC_CASE(10) HC_CASE(11) HC_CASE(12) HC_CASE(13) HC_CASE(14) HC_CASE(15) HC_CASE(16)
+#undef HC_CASE
+    default: break; // (lengths are below 2^11)
+    }
+  } else {
+    auto get = [&](int i) -> uint32_t { return y[i % 16]; };
+    switch (bw) {
+#define HC_CASE(B) case B: pack16_store<B, false>(get, data, words, last_mask, lane); break;
+      HC_CASE(1) HC_CASE(2) HC_CASE(3) HC_CASE(4) HC_CASE(5) HC_CASE(6) HC_CASE(7) HC_CASE(8)
+      HC_CASE(9) HC_CASE(10) HC_CASE(11) HC_CASE(12) HC_CASE(13) HC_CASE(14) HC_CASE(15) HC_CASE(16)
+      HC_CASE(32)
+#undef HC_CASE
+    default:
+      write_wide4(data, (const HC_LDS uint8_t*)X, n, bw, fr, words, last_mask, lane);
+      break;
+    }
   }
   return ob;
 }
@@ -800,6 +858,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, HC_CASC_OCC) void cascaded_
       uint32_t img = 0; // the chunk metadata image: lane j holds its word j (reference :1004-1014)
       uint32_t v[16];
       load16_global(in + (size_t)c * CB, n, v, lane);
+      // (Touching the next sub-chunk's lines here, so that its loads hit the L2 -- a wave meets the HBM's
+      // latency 16 times per partition -- made the kernel slower, 1958 -> 1825 GB/s: it is not what the
+      // waves wait for.)
       bool in_regs = true; // the array the next layer works on is in v (else: in X)
       int rr = R, dr = D;
       for (int l = 0; l < layers && use; ++l) {
@@ -1137,7 +1198,6 @@ __device__ __forceinline__ UT prefix_store_shifted(
 // markers: the runs of a lane behind the last run of the array (their bits read as 0) put their
 // markers at `total`, behind the output, where nothing looks -- entry 1024 when the sub-chunk is full.
 // ---------------------------------------------------------------------------
-#define HC_LDS __attribute__((address_space(3)))
 constexpr uint32_t kDec4Stage = 0, kDec4X = 1024, kDec4Marks = 1024 + kX4Bytes;
 constexpr uint32_t kDec4Bytes = kDec4Marks + 2048 + 16;
 
@@ -1213,7 +1273,56 @@ __device__ __forceinline__ void load_words(
   }
 }
 
-// The final array of a sub-chunk -> X (padded), 32 elements per lane.  Returns the count or -1.
+// The same 16 elements per lane (the encoder's pack16_store read backwards): the BW words of 32 elements
+// belong to a PAIR of lanes; the even lane's 16 elements begin at bit 0 of them, the odd lane's at bit
+// 16 BW -- word BW / 2 (rounded down), and where BW is odd 16 bits into that word: its words are then
+// moved down by 16 bits (one v_alignbit each).  H = the words 16 elements span.
+template <int BW>
+__device__ __forceinline__ uint32_t unpacked16(const uint32_t (&w)[BW == 0 ? 1 : (BW + 1) / 2], int k)
+{
+  if (BW == 0)
+    return 0u;
+  constexpr int H = BW == 0 ? 1 : (BW + 1) / 2;
+  const int p = k * BW, word = p >> 5, sh = p & 31;
+  uint32_t x = w[word % H] >> sh;
+  if (sh + BW > 32)
+    x |= w[(word + 1) % H] << (32 - sh);
+  return BW >= 32 ? x : x & ((1u << (BW & 31)) - 1u);
+}
+template <int BW, typename WordPtr>
+__device__ __forceinline__ void load_words16(
+    WordPtr data, uint32_t words, uint32_t n, uint32_t (&w)[BW == 0 ? 1 : (BW + 1) / 2], int lane)
+{
+  if (BW == 0) {
+    w[0] = 0;
+    return;
+  }
+  constexpr int H = BW == 0 ? 1 : (BW + 1) / 2;
+  const bool odd = (lane & 1) != 0;
+  const uint32_t w0 = (uint32_t)(lane >> 1) * BW + (odd ? (uint32_t)(BW / 2) : 0u);
+#pragma unroll
+  for (int j = 0; j < H; ++j)
+    w[j] = data[min(w0 + (uint32_t)j, words - 1u)];
+  if ((BW & 1) != 0) {
+#pragma unroll
+    for (int j = 0; j + 1 < H; ++j) {
+      const uint32_t down = __builtin_amdgcn_alignbit(w[j + 1], w[j], 16);
+      w[j] = odd ? down : w[j];
+    }
+    w[H - 1] = odd ? w[H - 1] >> 16 : w[H - 1];
+  }
+  // bits of mine that belong to elements: n BW minus where my 16 begin, clamped to [0, 16 BW]
+  const int32_t left = (int32_t)(n * BW) - (int32_t)(16u * (uint32_t)lane * BW);
+  if (left < 16 * BW) { // (the lane the array ends in, and the lanes behind it)
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const int32_t keep = left - 32 * j;
+      w[j] = keep >= 32 ? w[j] : (keep <= 0 ? 0u : w[j] & ((1u << (keep & 31)) - 1u));
+    }
+  }
+}
+
+// The final array of a sub-chunk -> X (padded), 16 elements per lane.  Returns the count or -1.
 // (out of line, with LDS-typed pointers: inlined, the 18 bit widths of this and of mark_run_starts4 in the
 // middle of the layer loop took the kernel to 300 registers; through generic pointers every access here
 // would be a flat_* one)
@@ -1225,16 +1334,16 @@ __device__ __noinline__ int unpack_values4(const HC_LDS uint32_t* src, uint32_t 
   const int n = open_array4<4>(src, nbytes, bp, 1024u, bw, fr, data, words);
   if (n <= 0)
     return n;
-  const uint32_t blocks = ((uint32_t)n + 31u) >> 5;
-  HC_LDS uint32_t* const mine = reinterpret_cast<HC_LDS uint32_t*>(X + (uint32_t)lane * 132u);
+  const uint32_t blocks = ((uint32_t)n + 15u) >> 4;
+  HC_LDS uint32_t* const mine = reinterpret_cast<HC_LDS uint32_t*>(X + ((uint32_t)lane * 16u + ((uint32_t)lane >> 1)) * 4u); // x4_addr(16 lane)
   auto go = [&](auto BWC) {
     constexpr int BW = decltype(BWC)::value;
     if ((uint32_t)lane < blocks) {
-      uint32_t w[BW == 0 ? 1 : BW];
-      load_words<BW>(data, words, (uint32_t)n, w, lane);
+      uint32_t w[BW == 0 ? 1 : (BW + 1) / 2];
+      load_words16<BW>(data, words, (uint32_t)n, w, lane);
 #pragma unroll
-      for (int k = 0; k < 32; ++k)
-        mine[k] = unpacked<BW>(w, k) + fr;
+      for (int k = 0; k < 16; ++k)
+        mine[k] = unpacked16<BW>(w, k) + fr;
     }
   };
   switch (bw) {
@@ -1290,26 +1399,26 @@ __device__ __noinline__ Runs4 mark_run_starts4(
   // could make one wrap is not an encoder's -- such a stream takes the element-per-lane code, -3)
   if (fr + (bw >= 16 ? 0xFFFFu : (1u << bw) - 1u) > 0xFFFFu)
     return Runs4{-3, 0u};
-  const uint32_t blocks = ((uint32_t)n + 31u) >> 5;
+  const uint32_t blocks = ((uint32_t)n + 15u) >> 4;
   const bool active = (uint32_t)lane < blocks;
-  const uint32_t nv = active ? min((uint32_t)n - 32u * (uint32_t)lane, 32u) : 0u; // my runs
+  const uint32_t nv = active ? min((uint32_t)n - 16u * (uint32_t)lane, 16u) : 0u; // my runs
   bool good = true;
   auto go = [&](auto BWC) {
     constexpr int BW = decltype(BWC)::value;
-    // my 32 lengths, then their running sums (behind the array's last run the bits read as 0: length =
+    // my 16 lengths, then their running sums (behind the array's last run the bits read as 0: length =
     // FOR there, taken off the lane's total again below)
-    uint32_t run[32];
+    uint32_t run[16];
     if (active) {
-      uint32_t w[BW == 0 ? 1 : BW];
-      load_words<BW>(data, words, (uint32_t)n, w, lane);
+      uint32_t w[BW == 0 ? 1 : (BW + 1) / 2];
+      load_words16<BW>(data, words, (uint32_t)n, w, lane);
 #pragma unroll
-      for (int k = 0; k < 32; ++k)
-        run[k] = unpacked<BW>(w, k) + fr;
+      for (int k = 0; k < 16; ++k)
+        run[k] = unpacked16<BW>(w, k) + fr;
 #pragma unroll
-      for (int k = 1; k < 32; ++k)
+      for (int k = 1; k < 16; ++k)
         run[k] += run[k - 1];
     }
-    const uint32_t lane_total = active ? run[31] - (32u - nv) * fr : 0u;
+    const uint32_t lane_total = active ? run[15] - (16u - nv) * fr : 0u;
     const uint32_t incl = wave_scan_add_u32(lane_total);
     total = read_lane(incl, 63);
     if (total > 1024u) { // (runs longer than the sub-chunk: reference :1371-1380 would write past its buffer)
@@ -1319,13 +1428,13 @@ __device__ __noinline__ Runs4 mark_run_starts4(
     if (active) {
       const uint32_t base = incl - lane_total;
       // A marker is the PADDED index of the run's value in the element buffer, plus one (0: no run starts
-      // here): 33 lane + k + 1 for run 32 lane + k -- it grows with the run like the run's number does, and
-      // the expansion needs no address arithmetic.  The runs of mine behind the array's last run start at or
-      // behind `total`: their markers go to `total`, behind the output (see the layout note above).
-      const uint32_t first = 33u * (uint32_t)lane + 1u;
+      // here): 16 lane + lane / 2 + k + 1 for run 16 lane + k -- it grows with the run like the run's number
+      // does, and the expansion needs no address arithmetic.  The runs of mine behind the array's last run
+      // start at or behind `total`: their markers go to `total`, behind the output (see the layout note above).
+      const uint32_t first = 16u * (uint32_t)lane + ((uint32_t)lane >> 1) + 1u;
       marks[base] = (uint16_t)first;
 #pragma unroll
-      for (int k = 1; k < 32; ++k)
+      for (int k = 1; k < 16; ++k)
         marks[min(base + run[k - 1], total)] = (uint16_t)(first + (uint32_t)k);
     }
   };
@@ -1728,6 +1837,15 @@ __device__ __forceinline__ void cascaded_decode_partition4(
       // sub-chunk -> output (outputs are 4-byte aligned: cascaded.h:178-193): four consecutive elements
       // per lane and step (they lie in one block of the padded layout), 1 KiB per store instruction
       HC_GLOBAL uint32_t* dst = reinterpret_cast<HC_GLOBAL uint32_t*>(out + (size_t)done * S);
+#ifndef HC_CASC_DEC_LATE_WAIT
+      // The words of the next sub-chunk, asked for at the top of this one, are here by now: have them
+      // waited for HERE, in front of this sub-chunk's stores.  Vector memory operations are counted in
+      // order, and a wait at the top of the next sub-chunk -- behind the stores -- is a wait for the
+      // stores to reach memory as well.
+#pragma unroll
+      for (int k = 0; k < (int)kStagePerLane; ++k)
+        asm volatile("" : "+v"(pf[k]));
+#endif
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint32_t e = 4u * ((uint32_t)lane + 64u * q);

@@ -37,6 +37,8 @@
 #include <atomic>
 #include <type_traits>
 
+#define HC_LDS __attribute__((address_space(3)))
+
 namespace hcamd {
 
 namespace {
@@ -442,6 +444,16 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t v, uint32_t last)
   return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130, 0xF, 0xF, false);
 }
 
+// element 64 k + lane + 1 for every lane, out of step k's register `cur` and step k + 1's `next`: the lane
+// above's `cur`, and for lane 63 lane 0's `next` -- which a rotation of `next` by one lane puts there (two
+// DPP moves; through v_readlane it was a third instruction, a copy into a vector register and two waits
+// for the scalar register in between)
+__device__ __forceinline__ uint32_t next_element(uint32_t cur, uint32_t next)
+{
+  const int rolled = __builtin_amdgcn_mov_dpp((int)next, 0x134, 0xF, 0xF, false);               // wave_rol:1 (every lane has a source)
+  return (uint32_t)__builtin_amdgcn_update_dpp(rolled, (int)cur, 0x130, 0xF, 0xF, false);       // wave_shl:1
+}
+
 // 64-lane reductions on the DPP crossbar: the result is lane 63's
 __device__ __forceinline__ int32_t wave_min_i32(int32_t v)
 {
@@ -493,6 +505,12 @@ __device__ __forceinline__ void load16_lds(const uint8_t* X, uint32_t n, uint32_
     if (64u * k < n)
       v[k] = *reinterpret_cast<const uint32_t*>(X + x4_addr(64u * k + (uint32_t)lane)); // (behind n: whatever lies there, in bounds)
   }
+  // (all of them waited for here, once: what follows stores to LDS under conditions between its uses of
+  // v[k], and the compiler, unable to count those stores, would wait for an empty LDS queue in front of
+  // every step)
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    asm volatile("" : "+v"(v[k]));
 }
 
 // v[k] <- element i + 1 minus element i (i = 64 k + lane): the delta layer on n >= 1 elements in
@@ -502,8 +520,7 @@ __device__ __forceinline__ void delta16(uint32_t (&v)[16], uint32_t n)
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     if (64u * k < n) {
-      const uint32_t first_above = k + 1 < 16 ? read_lane(v[(k + 1) % 16], 0) : 0u;
-      v[k] = from_lane_above(v[k], first_above) - v[k];
+      v[k] = (k + 1 < 16 ? next_element(v[k], v[(k + 1) % 16]) : from_lane_above(v[k], 0u)) - v[k];
     }
   }
 }
@@ -536,14 +553,18 @@ __device__ __forceinline__ void store16_lds(uint8_t* X, uint32_t n, const uint32
 __device__ __forceinline__ uint32_t rle16(const uint32_t (&v)[16], uint32_t n, uint8_t* X, uint8_t* Eb, int lane)
 {
   uint32_t m = 0, last = 0;
+  const uint32_t xbase = uniform((uint32_t)(uintptr_t)(const HC_LDS uint8_t*)X);
   // the run ends of a step: value and end position to consecutive ranks
   auto emit = [&](bool f, uint32_t cur, uint32_t end_pos) {
     const uint64_t ends = wave_ballot(f);
     if (f) {
       const uint32_t rank = lanes_below_me(ends, m);
-      const uint32_t pad4 = (rank >> 3) & ~3u; // 4 (rank / 32): the padding in front of the rank's block
-      *reinterpret_cast<uint32_t*>(X + ((rank << 2) + pad4)) = cur;
-      *reinterpret_cast<uint16_t*>(Eb + ((rank << 1) + pad4)) = (uint16_t)end_pos;
+      // X + 4 (rank / 32), the padding in front of the rank's block, as ONE instruction (the compiler makes
+      // three of it: shift, mask, add)
+      uint32_t padded;
+      asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(padded) : "v"(rank >> 5), "s"(xbase));
+      *reinterpret_cast<HC_LDS uint32_t*>((uintptr_t)(padded + (rank << 2))) = cur;
+      *reinterpret_cast<HC_LDS uint16_t*>((uintptr_t)(padded + (kX4Bytes + (rank << 1)))) = (uint16_t)end_pos; // (Eb = X + kX4Bytes)
     }
     m += (uint32_t)__builtin_popcountll(ends);
   };
@@ -551,7 +572,7 @@ __device__ __forceinline__ uint32_t rle16(const uint32_t (&v)[16], uint32_t n, u
   for (int k = 0; k < 16; ++k) {
     if (64u * k + 64u < n) { // (wave-uniform) a full step: every element has a right neighbour
       const uint32_t cur = v[k];
-      const uint32_t nx = from_lane_above(cur, read_lane(v[(k + 1) % 16], 0));
+      const uint32_t nx = next_element(cur, v[(k + 1) % 16]);
       emit(cur != nx, cur, 64u * k + 1u + (uint32_t)lane);
     } else if (64u * k < n) { // the last step: the last element ends a run whatever follows
       const uint32_t cur = v[k];
@@ -576,8 +597,6 @@ __device__ __forceinline__ uint32_t rle16(const uint32_t (&v)[16], uint32_t n, u
   lds_lane_exchange_fence();
   return m;
 }
-
-#define HC_LDS __attribute__((address_space(3)))
 
 // Bit packing, 16 elements per lane (reference block_bitpack :523-552: element i at bit i BW, LSB first).
 // A PAIR of lanes makes the BW words of 32 elements: the even lane packs elements [0, 16) from bit 0 on,

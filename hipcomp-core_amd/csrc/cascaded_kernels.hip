@@ -420,11 +420,12 @@ __device__ __forceinline__ uint32_t chunk_metadata_size(int R, int D)
 //    has a bank conflict.  What is stored per run is where it ENDS; lengths are differences of those
 //    and are taken by the packer in registers;
 //  * the compacted arrays lie in LDS with one dword of padding behind every 32 elements, so that
-//    the packer can take 32 consecutive elements per lane (132-byte / 68-byte lane stride: odd in
-//    dwords, conflict-free) -- 32 elements are a whole number of output words whatever the bit
-//    width, so a lane packs its elements without a neighbour, by compile-time shifts (one
-//    v_lshl_or_b32 per element for the bit widths met in practice), and minimum and maximum come
-//    out of the same registers: no pass of its own, no gather;
+//    the packer can take 16 consecutive elements per lane conflict-free (lanes 2 j and 2 j + 1 share a
+//    block of 32: 33 dwords from pair to pair) -- a PAIR of lanes makes the whole number of output
+//    words that 32 elements are whatever the bit width (pack16_store), by compile-time shifts (one
+//    v_lshl_or_b32 per element for the bit widths met in practice), and minimum and maximum come out
+//    of the same registers: no pass of its own, no gather.  (32 per lane, the first version: a sorted
+//    column's arrays have 700 - 800 elements, and 40 lanes of 64 had nothing to pack);
 //  * the chunk metadata image is a register (lane j = word j), not LDS: 4224 + 2176 bytes per wave,
 //    25 waves per CU as before.
 // ---------------------------------------------------------------------------

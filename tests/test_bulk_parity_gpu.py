@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 pytestmark = pytest.mark.gpu
 
-CHUNKS = int(os.environ.get("HIPCOMP_BULK_CHUNKS", "20000"))   # (profiles/r03_bulk_parity_100000.log: the same tests at 100 000)
+CHUNKS = int(os.environ.get("HIPCOMP_BULK_CHUNKS", "20000"))   # (profiles/r04_bulk_parity_100000.log: the same tests at 100 000)
 SEEDS = {"uniform": 0x5EED0002, "harness": 0x5EED0003, "runs": 0x5EED0004}
 
 

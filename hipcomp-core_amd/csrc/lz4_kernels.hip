@@ -410,6 +410,19 @@ extern "C" int hipcompBatchedLZ4DebugTripLog(uint32_t* host_words, uint32_t* cou
 }
 #endif
 
+#ifdef HC_MIX_STAMPS
+// (diagnostic build only; the name makes it pass the export map)
+extern "C" int hipcompBatchedLZ4DebugMixStamps(unsigned long long* host8, int reset)
+{
+  unsigned long long zeros[8] = {};
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_mix_stamps), sizeof(zeros)) != hipSuccess)
+    return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_mix_stamps), zeros, sizeof(zeros)) != hipSuccess)
+    return 2;
+  return 0;
+}
+#endif
+
 #ifdef HC_DEC_STAMPS
 // (diagnostic build only; the name makes it pass the export map)
 extern "C" int hipcompBatchedLZ4DebugDecodeStamps(unsigned long long* host8, int reset)

@@ -880,4 +880,13 @@ hipcompStatus_t hipcompHlifGetRequiredScratchBytes(hipcompHlifManager_t* manager
   return hipcompSuccess;
 }
 
+hipcompStatus_t hipcompHlifSetScratchBuffer(hipcompHlifManager_t* manager, void* device_scratch)
+{
+  static const char* fn = "hipcompHlifSetScratchBuffer()";
+  HCAMD_REQUIRE_NOT_NULL(fn, manager);
+  HCAMD_REQUIRE_NOT_NULL(fn, device_scratch);
+  manager->lz4->set_scratch_buffer(static_cast<uint8_t*>(device_scratch));
+  return hipcompSuccess;
+}
+
 } // extern "C"

@@ -48,6 +48,9 @@ hipcompStatus_t hipcompHlifDecompress(
 /* status of the manager's last compress / decompress; synchronises the stream */
 hipcompStatus_t hipcompHlifGetLastStatus(hipcompHlifManager_t* manager, hipcompStatus_t* status);
 hipcompStatus_t hipcompHlifGetRequiredScratchBytes(hipcompHlifManager_t* manager, size_t* scratch_bytes);
+/* hipcompManagerBase::set_scratch_buffer: the caller's buffer of hipcompHlifGetRequiredScratchBytes bytes
+   (device memory, 16-byte aligned) replaces the one the manager would allocate itself */
+hipcompStatus_t hipcompHlifSetScratchBuffer(hipcompHlifManager_t* manager, void* device_scratch);
 
 #ifdef __cplusplus
 }

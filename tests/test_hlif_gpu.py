@@ -180,6 +180,19 @@ def test_many_chunks_take_several_slabs(hc, cuda):
     need = c_size_t(0)
     assert L.hipcompHlifGetRequiredScratchBytes(m.h, ctypes.byref(need)) == 0 and need.value > 32768 * 1024
     m.close()
+    # the same with the caller's scratch buffer of exactly the required size (two slabs: the placing of one
+    # runs beside the compression of the next), guard bytes behind it
+    import torch
+    m = Manager(L, 1024, 0)
+    scratch = torch.full((need.value + 4096,), 0x5A, dtype=torch.uint8, device=cuda)
+    assert L.hipcompHlifSetScratchBuffer(m.h, c_void_p(scratch.data_ptr())) == 0
+    cont2, _ = m.compress(data, cuda)
+    a, b = _parse(cont), _parse(cont2)
+    assert a["sizes"] == b["sizes"] and a["offs"] == b["offs"] and cont2 == cont
+    st, back = m.decompress(cont2, cuda)
+    assert st == 0 and back == data
+    assert bool((scratch[need.value:] == 0x5A).all().item())       # nothing written behind the required size
+    m.close()
 
 
 @pytest.mark.skipif(not os.path.exists(REF_TOOL), reason="reference build of the high-level interface not present")

@@ -5,6 +5,7 @@
 // null exactly where the reference checks them (it does not call
 // hipPointerGetAttributes on this path).
 #include "hipcomp/snappy.h"
+#include "hipcomp/snappy_kernels.hpp"
 
 #include "host_common.hpp"
 #include "snappy_launch.hpp"
@@ -116,3 +117,49 @@ hipcompStatus_t hipcompBatchedSnappyCompressAsync(
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------
+// The reference's INTERNAL Snappy entry points (src/lowlevel/SnappyBatchKernels.h:80-148), the layer its
+// batched C functions call and its own tests/test_snappy_app.cpp and src/test/SnappyLargeTokens_test.cpp
+// are written against: exported under the same C++ names so that those programs compile unchanged (with
+// the reference's header, used in place) and link with this library (oracle/Makefile: _ref/cpp_unit_Snappy*).
+// Thin: the kernels are the batched API's.  Nothing is launched for count <= 0 (as there, :172, :192).
+// ---------------------------------------------------------------------------
+namespace hipcomp {
+
+void gpu_snap(
+    const void* const* device_in_ptr, const size_t* device_in_bytes, void* const* device_out_ptr,
+    const size_t* device_out_available_bytes, gpu_snappy_status_s* outputs, size_t* device_out_bytes, int count,
+    hipStream_t stream)
+{
+  if (count <= 0)
+    return;
+  hcamd::snappy_launch_compress(
+      reinterpret_cast<const uint8_t* const*>(device_in_ptr), device_in_bytes,
+      reinterpret_cast<uint8_t* const*>(device_out_ptr), device_out_bytes, (size_t)count, stream,
+      device_out_available_bytes, reinterpret_cast<uint32_t*>(outputs));
+}
+
+void gpu_unsnap(
+    const void* const* device_in_ptr, const size_t* device_in_bytes, void* const* device_out_ptr,
+    const size_t* device_out_available_bytes, hipcompStatus_t* outputs, size_t* device_out_bytes, int count,
+    hipStream_t stream)
+{
+  if (count <= 0)
+    return;
+  hcamd::snappy_launch_decompress(
+      reinterpret_cast<const uint8_t* const*>(device_in_ptr), device_in_bytes, device_out_available_bytes,
+      (size_t)count, reinterpret_cast<uint8_t* const*>(device_out_ptr), device_out_bytes, outputs, stream);
+}
+
+void gpu_get_uncompressed_sizes(
+    const void* const* device_in_ptr, const size_t* device_in_bytes, size_t* device_out_bytes, int count,
+    hipStream_t stream)
+{
+  if (count <= 0)
+    return;
+  hcamd::snappy_launch_get_sizes(
+      reinterpret_cast<const uint8_t* const*>(device_in_ptr), device_in_bytes, device_out_bytes, (size_t)count, stream);
+}
+
+} // namespace hipcomp

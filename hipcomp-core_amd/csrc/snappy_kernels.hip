@@ -83,7 +83,8 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     const uint8_t* const* __restrict__ in_ptrs,
     const size_t* __restrict__ in_bytes,
     uint8_t* const* __restrict__ out_ptrs,
-    size_t* __restrict__ out_bytes)
+    size_t* __restrict__ out_bytes,
+    const size_t* __restrict__ out_available, uint32_t* __restrict__ statuses)
 {
   __shared__ __attribute__((aligned(16))) uint16_t hash_map[kHashEntries];
 
@@ -92,6 +93,22 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
   cgptr __restrict__ src = to_global(uniform_ptr(in_ptrs[chunk]));
   const uint32_t len = uniform((uint32_t)in_bytes[chunk]);
   gptr __restrict__ dst = to_global(uniform_ptr(out_ptrs[chunk]));
+  // (only through hipcomp::gpu_snap, the reference's internal entry point -- the batched API has neither:
+  // reference compression.hiph:307-311 and :383 let the encoder run and report an output that did not
+  // fit; here a buffer smaller than the worst case for this input is not written to at all)
+  if (out_available != nullptr) {
+    const size_t room = uniform((uint64_t)out_available[chunk]);
+    if (room != 0 && room < (size_t)32 + len + len / 6) { // reference get_max_compressed_length
+      if (lane == 0) {
+        out_bytes[chunk] = 0;
+        if (statuses)
+          statuses[chunk] = 1;
+      }
+      return;
+    }
+  }
+  if (statuses != nullptr && lane == 0)
+    statuses[chunk] = 0;
 
   // varint of the uncompressed length (reference :316-322)
   uint32_t c = 0;
@@ -626,7 +643,7 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
       error = true;
     usize = uniform(usize);
     cur = uniform(cur);
-    size_t cap = uniform((uint64_t)out_caps[chunk]);
+    size_t cap = out_caps ? uniform((uint64_t)out_caps[chunk]) : 0; // (null: hipcomp::gpu_unsnap, "all have room")
     if (cap == 0)
       cap = usize; // reference decompression.hiph:148-149
     if ((cur >= end && usize != 0) || usize > cap)
@@ -935,10 +952,10 @@ __global__ __launch_bounds__(kWave * kDecompWavesPerBlock) void snappy_decompres
 void snappy_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, size_t batch,
-    hipStream_t stream)
+    hipStream_t stream, const size_t* out_available, uint32_t* statuses)
 {
   snappy_compress_kernel<<<dim3((unsigned)batch), dim3(kWave), 0, stream>>>(
-      in_ptrs, in_bytes, out_ptrs, out_bytes);
+      in_ptrs, in_bytes, out_ptrs, out_bytes, out_available, statuses);
 }
 
 void snappy_launch_decompress(

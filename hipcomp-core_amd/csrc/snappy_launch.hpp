@@ -12,7 +12,7 @@ namespace hcamd {
 void snappy_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, size_t batch,
-    hipStream_t stream);
+    hipStream_t stream, const size_t* out_available = nullptr, uint32_t* statuses = nullptr);
 
 void snappy_launch_decompress(
     const uint8_t* const* comp_ptrs, const size_t* comp_bytes,

@@ -55,6 +55,11 @@ def test_library_exports_exactly_the_declared_abi(hc):
     assert {"hipcomp::CompressionConfig::get_status", "hipcomp::DecompressionConfig::get_status",
             "hipcomp::create_manager"} <= hlif_classes
     classes -= hlif_classes
+    # the layer below the batched Snappy API (include/hipcomp/snappy_kernels.hpp; reference src/lowlevel/SnappyBatchKernels.h)
+    snappy_layer = {"hipcomp::gpu_snap", "hipcomp::gpu_unsnap", "hipcomp::gpu_get_uncompressed_sizes"}
+    header = open(os.path.join(ROOT, "include", "hipcomp", "snappy_kernels.hpp")).read()
+    assert snappy_layer <= classes and all(n.split("::")[1] + "(" in header for n in snappy_layer)
+    classes -= snappy_layer
     assert classes == {"hipcomp::RunLengthEncodeGPU::compress", "hipcomp::RunLengthEncodeGPU::compressDownstream",
                        "hipcomp::RunLengthEncodeGPU::requiredWorkspaceSize", "hipcomp::DeltaGPU::compress",
                        "hipcomp::DeltaGPU::requiredWorkspaceSize", "hipcomp::BitPackGPU::compress",

@@ -48,3 +48,26 @@ def test_reference_cpp_tests_pass_on_the_product_library(cuda, name):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert "All tests passed" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("name", ["RunLengthEncodeGPU_test", "DeltaGPU_test", "BitPackGPU_test",
+                                  "SnappyLargeTokens_test", "test_snappy_app"])
+def test_reference_unit_tests_pass_on_the_product_library(cuda, name):
+    """the reference's unit tests of its whole-array classes (src/test/*_test.cpp), compiled
+    UNCHANGED from where they lie -- hipcomp.hpp from this repo's include/, the class headers they name
+    (RunLengthEncodeGPU.h ...) the reference's own -- and linked with the product library
+    (oracle/Makefile: _ref/cpp_unit_*): the library exports the classes those headers declare, and they
+    behave as the reference's tests demand.  The same for the two programs written against the layer below
+    the batched Snappy API (hipcomp::gpu_snap / gpu_unsnap): src/test/SnappyLargeTokens_test.cpp (known
+    answers for literals and matches of 2^16 .. 2^24 bytes, both directions) and tests/test_snappy_app.cpp
+    (the decoder's golden vectors)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "cpp_unit_" + name)
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} absent (built by oracle/Makefile where /root/reference exists)")
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    bound = [ln for ln in ldd.splitlines() if "libhipcomp.so" in ln]
+    assert bound and os.path.realpath(bound[0].split("=>")[1].split("(")[0].strip()) == os.path.realpath(
+        os.path.join(ROOT, "hipcomp-core_amd", "lib", "libhipcomp.so")), ldd
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "All tests passed" in r.stdout, r.stdout[-2000:]

@@ -227,3 +227,17 @@ def test_option_selector_picks_what_measures_smallest(hc, cuda):
     # an empty batch: the defaults
     opts, ratio = lib.cascaded_select_opts(0, 0, 0, hc.hipcompType.INT, 0, 0, 0)
     assert (opts.num_RLEs, opts.num_deltas, opts.use_bp, ratio) == (2, 1, 1, 1.0)
+
+
+def test_random_partitions_of_every_bit_width(cuda):
+    """scripts/parity_sweep_cascaded.py, two rounds: random partitions built to meet every bit width of the
+    16-elements-per-lane packer / unpacker (values 1 .. 32 bits, run lengths 0 .. 10 bits, arrays ending in every
+    position of a block), all eight types x eight option sets -- kernel bytes == oracle bytes, the round trip,
+    and the kernel decoding the oracle's streams.  (profiles/r04_cascaded_parity_sweep.txt: forty rounds.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "parity_sweep_cascaded.py"), "2"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "TOTAL BAD 0" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -6,11 +6,18 @@
 // hipcompManagerFactory.cpp, the persistent-CTA
 // loop of src/hipcomp_common_deps/hlif_shared.hiph:165-232 (each CTA compresses a chunk into
 // its scratch slot, claims room in the container with an atomic on comp_data_size and copies
-// the chunk there: chunk data in completion order) and :293-345.  Here the chunk list goes
-// through the batched kernels a slab of chunks at a time: compress the slab into scratch
-// slots, scan the slab's sizes on top of comp_data_size, copy each chunk to its offset --
-// chunk data in chunk order, the same header, offsets and sizes arrays.  The scratch space is
-// one slab (a constant of the manager, as in the reference).
+// the chunk there: chunk data in completion order) and :293-345.
+// LZ4 (round 4): the same scheme inside the batched encoders -- a wave compresses into a slot of its own
+// (one per RESIDENT wave, not per chunk), takes the chunk's room in the container with an atomic add on
+// comp_data_size when the size is known, and copies it there; a chunk that ends in one long literal run
+// (data that does not compress) takes its room before that run is written and writes it in place, once
+// (lz4_launch.hpp: Lz4Placement; lz4_common.hiph: reserve_place / place_chunk).  Chunk data in completion
+// order, as in the reference.
+// Snappy, Cascaded: the chunk list goes through the batched kernels a slab of chunks at a time: compress
+// the slab into scratch slots, scan the slab's sizes on top of comp_data_size, copy each chunk to its
+// offset (on a stream of the manager's own, beside the compression of the next slab) -- chunk data in
+// chunk order, the same header, offsets and sizes arrays.  The scratch space is a constant of the
+// manager, as in the reference.
 #include "host_common.hpp"
 #include "lz4_launch.hpp"
 #include "wave_utils.hpp"
@@ -122,7 +129,8 @@ __global__ void slab_inputs_kernel(
   const uint64_t at = (first + i) * chunk_bytes;
   in_ptrs[i] = decomp + at;
   in_bytes[i] = (size_t)(decomp_bytes - at < chunk_bytes ? decomp_bytes - at : chunk_bytes);
-  out_ptrs[i] = slots + (uint64_t)i * slot_bytes;
+  if (out_ptrs)
+    out_ptrs[i] = slots + (uint64_t)i * slot_bytes;
 }
 
 // one workgroup: offsets of the slab's chunks = running total of the container + exclusive
@@ -334,7 +342,19 @@ struct Core
   }
   // what a caller's own scratch buffer must hold: two slabs (compress overlaps the placing of one
   // with the compression of the next)
-  size_t scratch_bytes() const { return scratch_bytes_for(slab, 2); }
+  size_t scratch_bytes() const
+  {
+    const size_t a = scratch_bytes_for(slab, 2), b = codec == LZ4 ? placed_scratch_bytes(kPlacedSlab) : 0;
+    return a > b ? a : b;
+  }
+  // LZ4: the encoders place the chunks themselves (lz4_launch.hpp, Lz4Placement) -- a slot per resident wave
+  // instead of one per chunk, no scan, no gather, no second stream; a pass takes up to kPlacedSlab chunks
+  // (what bounds it is the chunk lists and the launcher's routing lists, 40 bytes per chunk)
+  static constexpr size_t kPlacedSlab = 262144;
+  size_t placed_scratch_bytes(size_t chunks) const
+  {
+    return 16 * chunks + 64 + lz4_placement_slots() * slot_bytes + 16 + lz4_temp_bytes(chunks);
+  }
   // The manager's own scratch is as large as the calls so far needed (a buffer of a few chunks does not
   // pay for two slabs of 2 GiB); the caller's is scratch_bytes() by contract.
   size_t own_capacity = 0;
@@ -367,6 +387,10 @@ struct Core
     if (reinterpret_cast<uintptr_t>(comp_buffer) & 7)
       throw std::runtime_error("compress: the container buffer must be 8-byte aligned");
     const size_t n = cfg.num_chunks;
+    if (codec == LZ4) {
+      compress_placed(decomp_buffer, comp_buffer, cfg);
+      return;
+    }
     // (one slab: nothing to overlap, one set of slots)
     hipStream_t const placing = n > slab ? side_stream() : nullptr;
     const size_t per_set = n < slab ? (n ? n : 1) : slab;
@@ -433,6 +457,39 @@ struct Core
     for (int b = 0; b < 2; ++b)
       if (placing && used[b])
         check(hipStreamWaitEvent(stream, emptied[b], 0), "compress: wait for the container");
+    check(hipGetLastError(), "compress kernels");
+  }
+
+  // LZ4Manager::compress: see placed_scratch_bytes
+  void compress_placed(const uint8_t* decomp_buffer, uint8_t* comp_buffer, const hipcomp::CompressionConfig& cfg)
+  {
+    const size_t n = cfg.num_chunks;
+    const size_t per_pass = n < kPlacedSlab ? (n ? n : 1) : kPlacedSlab;
+    uint8_t* const s = ensure_scratch(placed_scratch_bytes(per_pass));
+    const Layout lay = layout(n);
+    const uint8_t** in_ptrs = reinterpret_cast<const uint8_t**>(s);
+    size_t* in_bytes = reinterpret_cast<size_t*>(s + per_pass * 8);
+    uint8_t* const slots = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(s + per_pass * 16 + 64) + 15) & ~uintptr_t(15));
+    uint8_t* lz4_temp = reinterpret_cast<uint8_t*>(
+        (reinterpret_cast<uintptr_t>(slots + lz4_placement_slots() * slot_bytes) + 15) & ~uintptr_t(15));
+    header_kernel<<<1, 1, 0, stream>>>(comp_buffer, cfg.uncompressed_buffer_size, n, chunk_bytes, (uint32_t)lay.data,
+                                       format, format_header, format_header_bytes, cfg.get_status());
+    for (size_t first = 0; first < n; first += per_pass) {
+      const uint32_t count = (uint32_t)(n - first < per_pass ? n - first : per_pass);
+      slab_inputs_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, stream>>>(
+          decomp_buffer, cfg.uncompressed_buffer_size, chunk_bytes, first, count, nullptr, 0, in_ptrs, in_bytes, nullptr);
+      Lz4Placement place;
+      place.slots = slots;
+      place.slot_bytes = slot_bytes;
+      place.data = comp_buffer + lay.data;
+      place.cursor = reinterpret_cast<unsigned long long*>(comp_buffer + offsetof(CommonHeader, comp_data_size));
+      place.offsets = reinterpret_cast<unsigned long long*>(comp_buffer + lay.offsets) + first;
+      place.align = place_align;
+      size_t* sizes = reinterpret_cast<size_t*>(comp_buffer + lay.sizes) + first;
+      check(lz4_launch_compress(in_ptrs, in_bytes, nullptr, sizes, ht_size, count, lz4_elem, lz4_temp, lz4_temp_bytes(per_pass),
+                                chunk_bytes, lz4_mode_from_environment(), stream, &place),
+            "LZ4Manager::compress");
+    }
     check(hipGetLastError(), "compress kernels");
   }
 

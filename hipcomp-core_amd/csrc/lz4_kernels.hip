@@ -117,10 +117,10 @@ namespace {
 
 typedef void (*MixKernel)(
     const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t, uint32_t,
-    uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint32_t*);
+    uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint32_t*, Lz4Placement);
 typedef void (*FarKernel)(const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint16_t*,
                           uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, const uint32_t*,
-                          const uint32_t*);
+                          const uint32_t*, Lz4Placement);
 
 MixKernel mix_kernel_for(int elem_size)
 {
@@ -495,6 +495,12 @@ void prefetch_side_end(PrefetchSide* side, hipStream_t stream)
 
 } // namespace
 
+size_t lz4_placement_slots()
+{
+  // (the far kernels: at most 32 waves per CU; the mix kernel 4)
+  return (size_t)num_cus_of_current_device() * 32u;
+}
+
 size_t lz4_compress_temp_bytes_used(uint32_t ht_size, size_t batch)
 {
   // header, the four class lists, alignment, one table per chunk but no more than the chip holds waves
@@ -507,8 +513,9 @@ hipError_t lz4_launch_compress(
     const uint8_t* const* in_ptrs, const size_t* in_bytes,
     uint8_t* const* out_ptrs, size_t* out_bytes, uint32_t ht_size,
     size_t batch, int elem_size, void* temp, size_t temp_bytes,
-    size_t max_chunk_bytes, Lz4Mode mode, hipStream_t stream)
+    size_t max_chunk_bytes, Lz4Mode mode, hipStream_t stream, const Lz4Placement* place_or_null)
 {
+  const Lz4Placement place = place_or_null ? *place_or_null : Lz4Placement();
   // ---- the temp buffer: header (ticket counters, list lengths, sample totals), the class
   // lists of the routing kernel, hash tables for the device-table waves of the far kernel --
   // as much of that as the (contract-sized) buffer holds
@@ -560,7 +567,7 @@ hipError_t lz4_launch_compress(
 #endif
     mix_kernel_for(elem_size)<<<grid, dim3(mix.waves() * kWave), mix.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
-        (uint32_t)batch, ticket, per_ticket, count, list);
+        (uint32_t)batch, ticket, per_ticket, count, list, place);
     if (side) {
       uint32_t waves = kPrefetchWaves, lead = kPrefetchLead, behind = kPrefetchBehind, nap = kPrefetchNap;
       uint32_t* trace = nullptr;
@@ -586,10 +593,12 @@ hipError_t lz4_launch_compress(
     far_kernel_for(elem_size, cls)<<<dim3(g.groups), dim3(g.waves() * kWave), g.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, g.near, g.slots,
         far_span(cls), (uint32_t)batch, header + cls,
-        chunks_per_ticket((size_t)g.groups * g.waves()), cls, counts, all_lists);
+        chunks_per_ticket((size_t)g.groups * g.waves()), cls, counts, all_lists, place);
     return true;
   };
   if (!header) { // (a temp buffer too small for a ticket counter)
+    if (place.slots) // (one slot per RESIDENT wave: needs the persistent grids)
+      return hipErrorInvalidValue;
     launch_mix(nullptr, nullptr);
     return hipSuccess;
   }

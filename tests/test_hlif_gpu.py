@@ -341,3 +341,30 @@ def test_factory_picks_the_lz4_manager_and_refuses_other_formats(hc, cuda):
     t = torch.from_numpy(np.frombuffer(bytes(bad), dtype=np.uint8).copy()).to(cuda)
     h = c_void_p()
     assert L.hipcompHlifManagerCreateFromContainer(c_void_p(t.data_ptr()), None, ctypes.byref(h)) == 10
+
+
+def test_lz4_placement_takes_several_passes_and_every_kind_of_chunk_end(hc, oracle, cuda):
+    """The LZ4 manager's encoders place their chunks themselves (lz4_launch.hpp, Lz4Placement), up to 262 144
+    chunks per pass: 600 000 chunks of 512 bytes are three passes.  Chunks that end in a literal run (placed
+    before that run is written), in a match (placed after), incompressible ones, empty tails: sizes = the
+    batched streams', places tile the data, the round trip."""
+    L = _lib(hc)
+    rng = np.random.default_rng(77)
+    chunk = 512
+    piece = (datagen.text_like(21, 1 << 20) + bytes(rng.integers(0, 256, 1 << 20, dtype=np.uint8))
+             + bytes(1 << 19) + datagen.harness_like_int32(22, 1 << 17).tobytes())
+    data = (piece * 200)[: 600000 * chunk - 77]
+    m = Manager(L, chunk, 0)
+    cont, nc = m.compress(data, cuda)
+    assert nc == 600000
+    h = _parse(cont)
+    assert h["comp_size"] == sum(h["sizes"]) and len(cont) == h["data_off"] + h["comp_size"]
+    order = np.argsort(np.asarray(h["offs"], dtype=np.int64), kind="stable")
+    offs, sizes = np.asarray(h["offs"], dtype=np.int64)[order], np.asarray(h["sizes"], dtype=np.int64)[order]
+    assert offs[0] == 0 and bool((offs[:-1] + sizes[:-1] == offs[1:]).all())
+    for i in list(range(0, nc, 9973)) + [nc - 1, 262143, 262144, 524287, 524288]:
+        blob = cont[h["data_off"] + h["offs"][i]: h["data_off"] + h["offs"][i] + h["sizes"][i]]
+        assert blob == oracle.lz4_compress(data[i * chunk:(i + 1) * chunk], 1, chunk), i
+    st, back = m.decompress(cont, cuda)
+    assert st == 0 and back == data
+    m.close()

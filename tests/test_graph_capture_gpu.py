@@ -1,0 +1,46 @@
+"""The batched calls inside a HIP graph: compress + decompress of a batch captured from a stream once and
+replayed -- nothing in the calls synchronises, allocates or reads the host (the LZ4 encoder's prefetch
+companion, which lives on a stream of the library's own, is left out of a capture: lz4_kernels.hip,
+prefetch_side_begin).  Every replay must give the sizes and the round trip of the plain calls."""
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("which", ["lz4-uniform", "lz4-harness", "snappy-text", "cascaded-sorted"])
+def test_compress_and_decompress_replay_from_a_graph(hc, cuda, which):
+    import torch
+    import bench
+    dev = torch.device("cuda:0")
+    if which == "lz4-uniform":      # the LDS-table kernel: 4 096 chunks is more than twice what the chip holds -> companion outside a capture
+        codec, opts, data = "LZ4", hc.LZ4Opts(0), bench.gen_data("uniform", 0, 4096, dev, 5)
+    elif which == "lz4-harness":
+        codec, opts, data = "LZ4", hc.LZ4Opts(0), bench.gen_data("harness", 0, 4096, dev, 6)
+    elif which == "snappy-text":
+        codec, opts, data = "Snappy", hc.SnappyOpts(0), torch.from_numpy(bench.gen_text(1024 * bench.CHUNK)).to(dev)
+    else:
+        codec, opts, data = "Cascaded", hc.CascadedOpts(4096, 5, 2, 1, 1), bench.gen_sorted_columns(2048, dev)
+    job = bench.CodecJob(hc, hc.default_library(), codec, opts, data)
+    job.compress(); job.decompress(); torch.cuda.synchronize()
+    job.verify()
+    want = job.comp.sizes.clone()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            job.compress()
+            job.decompress()
+    for _ in range(3):
+        job.comp.sizes.zero_()
+        job.out.data.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(job.comp.sizes, want)
+        job.verify()

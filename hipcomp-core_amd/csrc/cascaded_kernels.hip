@@ -1318,6 +1318,9 @@ __device__ __forceinline__ void load_words16(
     return;
   }
   constexpr int H = BW == 0 ? 1 : (BW + 1) / 2;
+  // (the lane number through an empty asm statement, as in pack16_store: what depends on it here, for each
+  // bit width, is not to be computed once in front of the loop over the sub-chunks and kept)
+  asm volatile("" : "+v"(lane));
   const bool odd = (lane & 1) != 0;
   const uint32_t w0 = (uint32_t)(lane >> 1) * BW + (odd ? (uint32_t)(BW / 2) : 0u);
 #pragma unroll
@@ -1343,10 +1346,13 @@ __device__ __forceinline__ void load_words16(
 }
 
 // The final array of a sub-chunk -> X (padded), 16 elements per lane.  Returns the count or -1.
-// (out of line, with LDS-typed pointers: inlined, the 18 bit widths of this and of mark_run_starts4 in the
-// middle of the layer loop took the kernel to 300 registers; through generic pointers every access here
-// would be a flat_* one)
-__device__ __noinline__ int unpack_values4(const HC_LDS uint32_t* src, uint32_t nbytes, int bp, HC_LDS uint8_t* X, int lane)
+// (LDS-typed pointers: through generic ones every access here would be a flat_* one.  Inlined -- for a
+// while this and mark_run_starts4 were out of line, because with 32 elements per lane the 18 bit widths of
+// each in the middle of the layer loop took the kernel to 300 registers; a call, though, waits for every
+// vector memory operation in flight on both sides of it (the callee may use any register), i.e. for
+// the words of the next sub-chunk asked for at the top of this one AND for the stores of the one before,
+// three times per sub-chunk: with 16 per lane they fit inline, 2 217 -> 2 637 GB/s)
+__device__ __forceinline__ int unpack_values4(const HC_LDS uint32_t* src, uint32_t nbytes, int bp, HC_LDS uint8_t* X, int lane)
 {
   typedef const HC_LDS uint32_t* WordPtr;
   uint32_t bw, fr, words = 0;
@@ -1404,7 +1410,7 @@ struct Runs4
   int n;          // number of runs; -1 / -2: malformed / too long; -3: take the element-per-lane code
   uint32_t total; // sum of the lengths
 };
-__device__ __noinline__ Runs4 mark_run_starts4(
+__device__ __forceinline__ Runs4 mark_run_starts4(
     const HC_LDS uint32_t* src, uint32_t nbytes, int bp, HC_LDS uint16_t* marks, int lane)
 {
   uint32_t total = 0; // (a local, returned by value: through a reference every use is a flat load)

@@ -8,10 +8,12 @@ import torch
 import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--chunks", type=int, default=100000)
+ap.add_argument("--dist", default="uniform", help="uniform | harness | runs | text (the far kernels: candidates come from the same few chunks too)")
 a = ap.parse_args()
 hc = importlib.import_module("hipcomp-core_amd")
 dev = torch.device("cuda:0")
-data = bench.gen_data("uniform", 0, a.chunks, dev, 0x5EED0002)
+data = (torch.from_numpy(bench.gen_text(a.chunks * bench.CHUNK)).to(dev) if a.dist == "text"
+        else bench.gen_data(a.dist, 0, a.chunks, dev, {"uniform": 0x5EED0002, "harness": 0x5EED0003, "runs": 0x5EED0004}[a.dist]))
 for dt, name in ((hc.hipcompType.CHAR, "char"), (hc.hipcompType.INT, "int")):
     job = bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(dt), data)
     job.compress(); torch.cuda.synchronize()
@@ -21,5 +23,5 @@ for dt, name in ((hc.hipcompType.CHAR, "char"), (hc.hipcompType.INT, "int")):
         job.src.ptrs[:] = job.src.ptrs[:k].repeat((a.chunks + k - 1) // k)[: a.chunks]   # inputs: k distinct chunks only
         job.compress(); torch.cuda.synchronize()
         tc2, _ = bench.time_phases(job, 5)
-        print(f"uniform {name} n={a.chunks}: compress {base:.3f} ms ({job.total / base / 1e6:.1f} GB/s); all inputs from {k} chunk(s) ({k * 64} KiB): {min(tc2):.3f} ms ({job.total / min(tc2) / 1e6:.1f} GB/s)", flush=True)
+        print(f"{a.dist} {name} n={a.chunks}: compress {base:.3f} ms ({job.total / base / 1e6:.1f} GB/s); all inputs from {k} chunk(s) ({k * 64} KiB): {min(tc2):.3f} ms ({job.total / min(tc2) / 1e6:.1f} GB/s)", flush=True)
     del job

@@ -8,14 +8,16 @@ import torch
 import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--chunks", type=int, default=100000)
+ap.add_argument("--codec", default="lz4", help="lz4 | snappy")
 ap.add_argument("--dist", default="uniform", help="uniform | harness | runs | text (the far kernels: candidates come from the same few chunks too)")
 a = ap.parse_args()
 hc = importlib.import_module("hipcomp-core_amd")
 dev = torch.device("cuda:0")
 data = (torch.from_numpy(bench.gen_text(a.chunks * bench.CHUNK)).to(dev) if a.dist == "text"
         else bench.gen_data(a.dist, 0, a.chunks, dev, {"uniform": 0x5EED0002, "harness": 0x5EED0003, "runs": 0x5EED0004}[a.dist]))
-for dt, name in ((hc.hipcompType.CHAR, "char"), (hc.hipcompType.INT, "int")):
-    job = bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(dt), data)
+for dt, name in ((hc.hipcompType.CHAR, "char"), (hc.hipcompType.INT, "int")) if a.codec == "lz4" else ((0, "snappy"),):
+    job = (bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(dt), data) if a.codec == "lz4"
+           else bench.CodecJob(hc, hc.default_library(), "Snappy", hc.SnappyOpts(0), data))
     job.compress(); torch.cuda.synchronize()
     tc, _ = bench.time_phases(job, 5)
     base = min(tc)

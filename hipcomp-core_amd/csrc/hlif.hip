@@ -551,7 +551,10 @@ struct Core
       const size_t* sizes = reinterpret_cast<const size_t*>(comp_buffer + lay.sizes) + first;
       switch (codec) {
       case LZ4:
-        lz4_launch_decompress(comp_ptrs, sizes, caps, count, out_ptrs, actual, statuses, true, stream);
+        // (the 64 spare bytes behind the chunk lists hold the decoder's chunk ticket counter)
+        check(lz4_launch_decompress(comp_ptrs, sizes, caps, count, out_ptrs, actual, statuses, true, stream,
+                                    s + (size_t)slab * 44, 64),
+              "LZ4Manager::decompress");
         break;
       case Snappy:
         if (hipcompBatchedSnappyDecompressAsync(reinterpret_cast<const void* const*>(comp_ptrs), sizes, caps, actual, count,

@@ -145,7 +145,7 @@ hipcompStatus_t hipcompBatchedLZ4DecompressAsync(
     const size_t* device_compressed_bytes,
     const size_t* device_uncompressed_bytes,
     size_t* device_actual_uncompressed_bytes, size_t batch_size,
-    void* const device_temp_ptr, size_t /*temp_bytes*/,
+    void* const device_temp_ptr, size_t temp_bytes,
     void* const* device_uncompressed_ptrs, hipcompStatus_t* device_statuses,
     hipStream_t stream)
 {
@@ -164,11 +164,13 @@ hipcompStatus_t hipcompBatchedLZ4DecompressAsync(
   if (batch_size == 0)
     return hipcompSuccess;
 
-  lz4_launch_decompress(
-      reinterpret_cast<const uint8_t* const*>(device_compressed_ptrs),
-      device_compressed_bytes, device_uncompressed_bytes, batch_size,
-      reinterpret_cast<uint8_t* const*>(device_uncompressed_ptrs),
-      device_actual_uncompressed_bytes, device_statuses, true, stream);
+  if (lz4_launch_decompress(
+          reinterpret_cast<const uint8_t* const*>(device_compressed_ptrs),
+          device_compressed_bytes, device_uncompressed_bytes, batch_size,
+          reinterpret_cast<uint8_t* const*>(device_uncompressed_ptrs),
+          device_actual_uncompressed_bytes, device_statuses, true, stream, device_temp_ptr, temp_bytes)
+      != hipSuccess)
+    return fail(fn, "could not zero the chunk ticket counter in the temp buffer");
   std::string why;
   if (!launch_ok("lz4 decompress kernel", why))
     return fail(fn, why);
@@ -190,7 +192,7 @@ hipcompStatus_t hipcompBatchedLZ4GetDecompressSizeAsync(
   if (batch_size == 0)
     return hipcompSuccess;
 
-  lz4_launch_decompress(
+  (void)lz4_launch_decompress( // (no temp buffer in this call: one wave per chunk by position, nothing to fail)
       reinterpret_cast<const uint8_t* const*>(device_compressed_ptrs),
       device_compressed_bytes, nullptr, batch_size, nullptr,
       device_uncompressed_bytes, nullptr, false, stream);

@@ -74,10 +74,13 @@ hipError_t lz4_launch_compress(
 size_t lz4_compress_temp_bytes_used(uint32_t ht_size, size_t batch);
 
 // write_out == false: parse-only pass that reports sizes.
-void lz4_launch_decompress(
+// `temp` / `temp_bytes`: the caller's temp buffer (hipcompBatchedLZ4DecompressGetTempSize bytes by contract; 4
+// of them are used: a chunk ticket counter, zeroed on the stream); nullptr / too small: accepted, one wave
+// per chunk by its position in the grid.
+hipError_t lz4_launch_decompress(
     const uint8_t* const* comp_ptrs, const size_t* comp_bytes,
     const size_t* out_caps, size_t batch, uint8_t* const* out_ptrs,
     size_t* actual_bytes, hipcompStatus_t* statuses, bool write_out,
-    hipStream_t stream);
+    hipStream_t stream, void* temp = nullptr, size_t temp_bytes = 0);
 
 } // namespace hcamd

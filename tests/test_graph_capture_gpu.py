@@ -44,3 +44,29 @@ def test_compress_and_decompress_replay_from_a_graph(hc, cuda, which):
         torch.cuda.synchronize()
         assert torch.equal(job.comp.sizes, want)
         job.verify()
+
+
+def test_decompress_then_compress_in_one_graph(hc, cuda):
+    """The other order: a compress call captured BEHIND a decompress call's kernels (its ticket counters are
+    zeroed by a kernel of its own on the stream, like the decoder's)."""
+    import torch
+    import bench
+    dev = torch.device("cuda:0")
+    a = bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(0), bench.gen_data("harness", 0, 3000, dev, 8))
+    b = bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(0), bench.gen_data("uniform", 0, 3000, dev, 9))
+    a.compress(); a.decompress(); b.compress(); b.decompress(); torch.cuda.synchronize()
+    a.verify(); b.verify()
+    want = b.comp.sizes.clone()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            a.decompress()
+            b.compress()
+            b.decompress()
+    for _ in range(3):
+        a.out.data.zero_(); b.comp.sizes.zero_(); b.out.data.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(b.comp.sizes, want)
+        a.verify(); b.verify()

@@ -11,6 +11,8 @@ itself never touches an AGPR in those kernels -- not to spill a vector register
 
   mix   every mention of an AGPR lies INSIDE an inline-asm block (";;#ASMSTART" ..
         ";;#ASMEND"), .num_agpr == 24, no scratch, <= 256 VGPRs;
+  pair  the same with .num_agpr == 26 (a24, a25: the early look at the pair's token) and
+        VGPRs + AGPRs <= 256: two waves per SIMD;
   far   no AGPR at all, no scratch, <= 64 VGPRs (eight waves per SIMD);
   all   no *_d16 loads (table entries are read zero-extended: walk_probe relies on it).
 
@@ -48,13 +50,16 @@ def main(path):
     for m in re.finditer(r"\.set (\S+)\.(num_agpr|num_vgpr|private_seg_size), (\d+)", text):
         sets.setdefault(m.group(1), {})[m.group(2)] = int(m.group(3))
     mix = [k for k in ks if "lz4_compress_kernel_mix" in k]
+    pair = [k for k in ks if "lz4_compress_kernel_pair" in k]
     far = [k for k in ks if "lz4_compress_kernel_far" in k or "lz4_compress_kernel_near" in k
            or "lz4_compress_kernel_both" in k]
     if len(mix) != 3:
         errors.append(f"expected 3 mix kernels (element size 1, 2, 4), found {len(mix)}")
     if len(far) < 9:
         errors.append(f"expected at least 9 far kernels (3 element sizes x lean, lean with chains, wide), found {len(far)}")
-    for k in mix + far:
+    if len(pair) != 3:
+        errors.append(f"expected 3 pair kernels (element size 1, 2, 4), found {len(pair)}")
+    for k in mix + pair + far:
         s = sets.get(k, {})
         in_asm = False
         for ln in ks[k]:
@@ -75,6 +80,13 @@ def main(path):
                 errors.append(f"{k}: num_agpr {s.get('num_agpr')} != 24")
             if s.get("num_vgpr", 999) > 256:
                 errors.append(f"{k}: num_vgpr {s.get('num_vgpr')} > 256")
+        elif k in pair:
+            # two waves per SIMD: vector + accumulation registers within 256 (the ring a0..a23 and the
+            # token look a24, a25)
+            if s.get("num_agpr") != 26:
+                errors.append(f"{k}: num_agpr {s.get('num_agpr')} != 26")
+            if (s.get("num_vgpr", 999) + 7) // 8 * 8 + 26 > 256:
+                errors.append(f"{k}: num_vgpr {s.get('num_vgpr')} + 26 accumulation registers > 256 (two waves per SIMD)")
         else:
             if s.get("num_agpr") != 0:
                 errors.append(f"{k}: num_agpr {s.get('num_agpr')} != 0")

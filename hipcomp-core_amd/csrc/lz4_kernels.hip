@@ -57,6 +57,10 @@
 #include "lz4_launch.hpp"
 #include "wave_utils.hpp"
 
+#ifndef HC_PAIR_DEFAULT
+#define HC_PAIR_DEFAULT 1
+#endif
+
 #include <atomic>
 #include <mutex>
 #include <cstdio>
@@ -121,6 +125,16 @@ typedef void (*MixKernel)(
 typedef void (*FarKernel)(const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint16_t*,
                           uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, const uint32_t*,
                           const uint32_t*, Lz4Placement);
+
+typedef void (*PairKernel)(
+    const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t,
+    uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint32_t*, Lz4Placement);
+
+PairKernel pair_kernel_for(int elem_size)
+{
+  return elem_size == 1 ? lz4_compress_kernel_pair<1> : elem_size == 2 ? lz4_compress_kernel_pair<2>
+                                                                      : lz4_compress_kernel_pair<4>;
+}
 
 MixKernel mix_kernel_for(int elem_size)
 {
@@ -223,6 +237,38 @@ Lz4CompressShape lz4_compress_shape_mix(uint32_t ht_size, size_t batch)
   sh.lds_bytes = sh.tagged * sh.stride_tagged + sh.plain * sh.stride_plain;
   set_groups(sh, batch);
   return sh;
+}
+
+// The pair shape (lz4_mix.hiph, lz4_compress_kernel_pair): one chunk per workgroup of two waves.
+// `tagged`: with a tag table (64 KiB chunks: three workgroups per CU instead of four).
+struct Lz4PairShape
+{
+  uint32_t tagged, table_bytes, lds_bytes, groups;
+};
+Lz4PairShape lz4_compress_shape_pair(uint32_t ht_size, size_t batch, bool tagged)
+{
+  Lz4PairShape sh;
+  sh.tagged = tagged ? 1u : 0u;
+  sh.table_bytes = round_up(ht_size * (tagged ? 3u : 2u), 16u);
+  sh.lds_bytes = sh.table_bytes + 64u; // (kPairSyncBytes)
+  uint32_t per_cu = kLdsPerCu / round_up(sh.lds_bytes, kLdsGranule);
+  if (per_cu > 8)
+    per_cu = 8;
+  const size_t cap = (size_t)num_cus_of_current_device() * per_cu;
+  sh.groups = (uint32_t)(batch < cap ? batch : cap);
+  return sh;
+}
+
+// 0: the mix kernel of rounds 1-4 (four lone waves per CU); 1: pairs with tag tables; 2: pairs without.
+// Pairs only where a chunk's table is large enough for LDS to be what limits the waves per CU.
+int lz4_pair_mode(uint32_t ht_size)
+{
+  int mode = HC_PAIR_DEFAULT;
+#ifdef HC_MEASUREMENT_KNOBS
+  if (const char* e = std::getenv("HIPCOMP_LZ4_PAIR"))
+    mode = std::atoi(e);
+#endif
+  return ht_size >= 8192 ? mode : 0;
 }
 
 // The library that ships reads nothing from the environment: every chunk goes where the routing
@@ -410,6 +456,19 @@ extern "C" int hipcompBatchedLZ4DebugTripLog(uint32_t* host_words, uint32_t* cou
 }
 #endif
 
+#ifdef HC_PAIR_DEBUG
+// (diagnostic build only; the name makes it pass the export map)
+extern "C" int hipcompBatchedLZ4DebugPair(uint32_t* host16, int reset)
+{
+  uint32_t zeros[32] = {};
+  if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_pair_dbg), sizeof(zeros)) != hipSuccess)
+    return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_pair_dbg), zeros, sizeof(zeros)) != hipSuccess)
+    return 2;
+  return 0;
+}
+#endif
+
 #ifdef HC_MIX_STAMPS
 // (diagnostic build only; the name makes it pass the export map)
 extern "C" int hipcompBatchedLZ4DebugMixStamps(unsigned long long* host8, int reset)
@@ -482,6 +541,16 @@ PrefetchSide* prefetch_side_begin(hipStream_t stream)
   return nullptr;
 }
 
+// (measurement knob HIPCOMP_PREFETCH=0, knobs build only: no companion)
+bool prefetch_wanted()
+{
+#ifdef HC_MEASUREMENT_KNOBS
+  if (const char* e = std::getenv("HIPCOMP_PREFETCH"))
+    return std::atoi(e) != 0;
+#endif
+  return true;
+}
+
 void prefetch_side_end(PrefetchSide* side, hipStream_t stream)
 {
   // (if the record fails the caller's stream cannot be made to wait: wait here, once, rather than let the
@@ -550,6 +619,8 @@ hipError_t lz4_launch_compress(
   if (raised != hipSuccess)
     return raised;
   const Lz4CompressShape mix = lz4_compress_shape_mix(ht_size, batch);
+  const int pair_mode = lz4_pair_mode(ht_size);
+  const Lz4PairShape pair = lz4_compress_shape_pair(ht_size, batch, pair_mode == 1 || pair_mode == 3); // (3: debug, wave 0 walks alone)
   // about 16 KiB of input per ticket, but at least 4 tickets per wave so
   // that the last ones even out the load
   auto chunks_per_ticket = [&](size_t all_waves) {
@@ -563,14 +634,20 @@ hipError_t lz4_launch_compress(
     uint32_t* ticket = header ? header + kClassMix : nullptr;
     // ticket == nullptr: no persistent workgroups, one chunk per wave
     const dim3 grid(ticket ? mix.groups : (unsigned)((batch + mix.waves() - 1) / mix.waves()));
-    const uint32_t per_ticket = chunks_per_ticket((size_t)mix.groups * mix.waves());
+    const size_t resident = pair_mode != 0 ? (size_t)pair.groups : (size_t)mix.groups * mix.waves(); // chunks in flight
+    const uint32_t per_ticket = chunks_per_ticket(resident);
     // the prefetch companion (lz4_mix.hiph): only where the kernel works through a list of whole tickets
     // that is longer than the chip holds at once
     PrefetchSide* side = nullptr;
 #ifndef HC_MIX_NO_PREFETCH
-    if (ticket && count && per_ticket == 1 && batch > 2 * (size_t)mix.groups * mix.waves())
+    if (ticket && count && per_ticket == 1 && batch > 2 * resident && prefetch_wanted())
       side = prefetch_side_begin(stream);
 #endif
+    if (pair_mode != 0)
+      pair_kernel_for(elem_size)<<<dim3(ticket ? pair.groups : (unsigned)batch), dim3(2 * kWave), pair.lds_bytes, stream>>>(
+          in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, pair.tagged | (pair_mode >= 3 ? 2u : 0u), pair.table_bytes,
+          (uint32_t)batch, ticket, per_ticket, count, list, place);
+    else
     mix_kernel_for(elem_size)<<<grid, dim3(mix.waves() * kWave), mix.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
         (uint32_t)batch, ticket, per_ticket, count, list, place);

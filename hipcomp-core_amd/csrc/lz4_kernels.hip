@@ -57,12 +57,8 @@
 #include "lz4_launch.hpp"
 #include "wave_utils.hpp"
 
-#ifndef HC_PAIR_DEFAULT
-#define HC_PAIR_DEFAULT 1
-#endif
 
 #include <atomic>
-#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -260,15 +256,21 @@ Lz4PairShape lz4_compress_shape_pair(uint32_t ht_size, size_t batch, bool tagged
 }
 
 // 0: the mix kernel of rounds 1-4 (four lone waves per CU); 1: pairs with tag tables; 2: pairs without.
-// Pairs only where a chunk's table is large enough for LDS to be what limits the waves per CU.
-int lz4_pair_mode(uint32_t ht_size)
+// Pairs where they are not slower than the lone waves (scripts/sweep_pair.py, profiles/r05_pair_sweep.txt):
+// chunks of more than 32 KiB (the walk is what the second wave shares; the rest of a chunk's work is wave
+// 0's alone: 32 KiB chunks 415 against 429 GB/s, 64 KiB 466 against 421) and of at most 64 KiB (longer chunks
+// take the walk of one wave), and a batch of two rounds or more of the 3 pairs a CU holds (four lone waves
+// hold a chunk more: 1000 x 64 KiB 268 against 338 GB/s, 1500: 360 against 338).
+int lz4_pair_mode(uint32_t ht_size, size_t max_chunk_bytes, size_t batch)
 {
-  int mode = HC_PAIR_DEFAULT;
+  int mode = ht_size >= 16384 && max_chunk_bytes > 32768 && max_chunk_bytes <= 65536
+                     && batch >= 2u * 3u * (size_t)num_cus_of_current_device()
+                 ? 1 : 0;
 #ifdef HC_MEASUREMENT_KNOBS
   if (const char* e = std::getenv("HIPCOMP_LZ4_PAIR"))
-    mode = std::atoi(e);
+    mode = ht_size >= 8192 ? std::atoi(e) : 0;
 #endif
-  return ht_size >= 8192 ? mode : 0;
+  return mode;
 }
 
 // The library that ships reads nothing from the environment: every chunk goes where the routing
@@ -495,75 +497,6 @@ extern "C" int hipcompBatchedLZ4DebugDecodeStamps(unsigned long long* host8, int
 }
 #endif
 
-namespace {
-// ---- the side stream of the prefetch kernel (lz4_mix.hiph) ------------------------------------------
-// One non-blocking stream and two events per device, made on first use and kept.  A call brackets the
-// prefetch kernel with them: the side stream waits for everything the caller's stream holds so far (the
-// header's memset, the routing kernel), the caller's stream waits for the prefetch kernel at the end --
-// so whatever the caller does next, on this stream or after synchronising it, comes after the last read
-// of its arrays.  Nothing here waits on the host.  The record/wait pairs of one call are made under the
-// lock: two host threads share the events, and a wait takes the most recent record.
-// Whatever fails, the call goes on without the companion (it only ever changes speed); a stream that is
-// being captured into a graph goes without as well.
-constexpr int kMostDevices = 64;
-struct PrefetchSide
-{
-  hipStream_t stream = nullptr;
-  hipEvent_t begin = nullptr, end = nullptr;
-  bool tried = false, usable = false;
-};
-std::mutex g_prefetch_lock;
-PrefetchSide g_prefetch_sides[kMostDevices];
-
-// -> the side stream, already waiting for `stream`'s work so far, with the lock HELD; or nullptr
-PrefetchSide* prefetch_side_begin(hipStream_t stream)
-{
-  int device = -1;
-  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMostDevices
-      || hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  g_prefetch_lock.lock();
-  PrefetchSide& side = g_prefetch_sides[device];
-  if (!side.tried) {
-    side.tried = true;
-    side.usable = hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking) == hipSuccess
-                  && hipEventCreateWithFlags(&side.begin, hipEventDisableTiming) == hipSuccess
-                  && hipEventCreateWithFlags(&side.end, hipEventDisableTiming) == hipSuccess;
-  }
-  if (side.usable && hipEventRecord(side.begin, stream) == hipSuccess
-      && hipStreamWaitEvent(side.stream, side.begin, 0) == hipSuccess)
-    return &side;
-  (void)hipGetLastError();
-  g_prefetch_lock.unlock();
-  return nullptr;
-}
-
-// (measurement knob HIPCOMP_PREFETCH=0, knobs build only: no companion)
-bool prefetch_wanted()
-{
-#ifdef HC_MEASUREMENT_KNOBS
-  if (const char* e = std::getenv("HIPCOMP_PREFETCH"))
-    return std::atoi(e) != 0;
-#endif
-  return true;
-}
-
-void prefetch_side_end(PrefetchSide* side, hipStream_t stream)
-{
-  // (if the record fails the caller's stream cannot be made to wait: wait here, once, rather than let the
-  // prefetch kernel outlive the call)
-  if (hipEventRecord(side->end, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->end, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    (void)hipStreamSynchronize(side->stream);
-  }
-  g_prefetch_lock.unlock();
-}
-
-} // namespace
-
 // words[0 .. blockDim.x) = 0: the ticket counters of a call, on its stream
 __global__ void lz4_zero_words_kernel(uint32_t* words)
 {
@@ -619,8 +552,8 @@ hipError_t lz4_launch_compress(
   if (raised != hipSuccess)
     return raised;
   const Lz4CompressShape mix = lz4_compress_shape_mix(ht_size, batch);
-  const int pair_mode = lz4_pair_mode(ht_size);
-  const Lz4PairShape pair = lz4_compress_shape_pair(ht_size, batch, pair_mode == 1 || pair_mode == 3); // (3: debug, wave 0 walks alone)
+  const int pair_mode = lz4_pair_mode(ht_size, max_chunk_bytes, batch);
+  const Lz4PairShape pair = lz4_compress_shape_pair(ht_size, batch, pair_mode == 1);
   // about 16 KiB of input per ticket, but at least 4 tickets per wave so
   // that the last ones even out the load
   auto chunks_per_ticket = [&](size_t all_waves) {
@@ -636,38 +569,14 @@ hipError_t lz4_launch_compress(
     const dim3 grid(ticket ? mix.groups : (unsigned)((batch + mix.waves() - 1) / mix.waves()));
     const size_t resident = pair_mode != 0 ? (size_t)pair.groups : (size_t)mix.groups * mix.waves(); // chunks in flight
     const uint32_t per_ticket = chunks_per_ticket(resident);
-    // the prefetch companion (lz4_mix.hiph): only where the kernel works through a list of whole tickets
-    // that is longer than the chip holds at once
-    PrefetchSide* side = nullptr;
-#ifndef HC_MIX_NO_PREFETCH
-    if (ticket && count && per_ticket == 1 && batch > 2 * resident && prefetch_wanted())
-      side = prefetch_side_begin(stream);
-#endif
     if (pair_mode != 0)
       pair_kernel_for(elem_size)<<<dim3(ticket ? pair.groups : (unsigned)batch), dim3(2 * kWave), pair.lds_bytes, stream>>>(
-          in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, pair.tagged | (pair_mode >= 3 ? 2u : 0u), pair.table_bytes,
+          in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, pair.tagged, pair.table_bytes,
           (uint32_t)batch, ticket, per_ticket, count, list, place);
     else
     mix_kernel_for(elem_size)<<<grid, dim3(mix.waves() * kWave), mix.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
         (uint32_t)batch, ticket, per_ticket, count, list, place);
-    if (side) {
-      uint32_t waves = kPrefetchWaves, lead = kPrefetchLead, behind = kPrefetchBehind, nap = kPrefetchNap;
-      uint32_t* trace = nullptr;
-      uint32_t trace_words = 0;
-#ifdef HC_MEASUREMENT_KNOBS
-      if (const char* e = std::getenv("HIPCOMP_PREFETCH_WAVES")) waves = (uint32_t)std::atoi(e);
-      if (const char* e = std::getenv("HIPCOMP_PREFETCH_LEAD")) lead = (uint32_t)std::atoi(e);
-      if (const char* e = std::getenv("HIPCOMP_PREFETCH_BEHIND")) behind = (uint32_t)std::atoi(e);
-      if (const char* e = std::getenv("HIPCOMP_PREFETCH_NAP")) nap = (uint32_t)std::atoi(e);
-      // (the ticket counter over time, into the dense class's list -- empty on the data this is used with)
-      if (std::getenv("HIPCOMP_PREFETCH_TRACE") && lists) { trace = lists + kClassDense * batch; trace_words = (uint32_t)batch; }
-#endif
-      // (one wave more: the one that watches the ticket counter for the others)
-      lz4_prefetch_kernel<<<dim3(waves + 1u), dim3(kWave), 0, side->stream>>>(
-          in_ptrs, in_bytes, (uint32_t)batch, ticket, header + kHeaderPublished, count, list, lead, behind, nap, trace, trace_words);
-      prefetch_side_end(side, stream);
-    }
   };
   auto launch_far = [&](uint32_t cls, const uint32_t* counts, const uint32_t* all_lists) -> bool {
     const FarGeometry g = far_geometry(ht_size, cls, batch, far_tables ? far_capacity : 0);

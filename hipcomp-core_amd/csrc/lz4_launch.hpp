@@ -12,6 +12,8 @@ namespace hcamd {
 // compute units of the calling thread's current device (cached per device; lz4_kernels.hip)
 int num_cus_of_current_device();
 
+// (The "pair" shape -- lz4_mix.hiph, lz4_compress_kernel_pair: two waves per chunk, one chunk per workgroup -- is
+// what data without matches meets in chunks of 16 .. 64 KiB and batches of several thousand; else "mix":)
 // Most waves (= chunks in flight) one compression workgroup of the "mix" shape
 // holds.  Four (one per SIMD): the kernel may then use up to 256 vector
 // registers and keeps clear of the accumulation registers, which its walk uses
@@ -42,8 +44,8 @@ Lz4Mode lz4_mode_from_environment();
 
 // `temp` / `temp_bytes`: the caller's temp buffer (hipcompBatchedLZ4CompressGetTempSize bytes by
 // contract), used while the call runs as far as it goes: 64 words of header -- a chunk ticket
-// counter and a list length per launch shape, sample totals, the word of the prefetch kernel's first
-// wave (lz4_far.hiph, kHeaderWords) -- zeroed by the launcher on the stream, the routing kernel's lists (4 x batch words), and hash tables for the far kernel's
+// counter and a list length per launch shape, sample totals (lz4_far.hiph, kHeaderWords) -- zeroed by the
+// launcher on the stream, the routing kernel's lists (4 x batch words), and hash tables for the far kernel's
 // device-table waves (max(ht_size, 8) uint16 each, 16-byte aligned).  Too small for the lists:
 // no routing, the LDS shape for all; too small for the header: one chunk per wave.  nullptr / 0
 // is accepted (the same).  batch must be > 0 and < 2^31.

@@ -30,7 +30,11 @@ def test_shipped_object_passed_the_register_guard():
     text = open(ASM).read()
     agprs = dict(re.findall(r"\.set (\S*lz4_compress_kernel_\S*)\.num_agpr, (\d+)", text))
     assert {v for k, v in agprs.items() if "kernel_mix" in k} == {"24"}
-    assert {v for k, v in agprs.items() if "kernel_mix" not in k} == {"0"}
+    assert {v for k, v in agprs.items() if "kernel_pair" in k} == {"26"}   # (+ a24, a25: the early look at the pair's token)
+    assert {v for k, v in agprs.items() if "kernel_mix" not in k and "kernel_pair" not in k} == {"0"}
+    # the pair kernels run two waves per SIMD: vector + accumulation registers within 256
+    vgprs = dict(re.findall(r"\.set (\S*lz4_compress_kernel_pair\S*)\.num_vgpr, (\d+)", text))
+    assert len(vgprs) == 3 and all((int(v) + 7) // 8 * 8 + 26 <= 256 for v in vgprs.values()), vgprs
 
 
 def test_makefile_runs_the_guard_on_the_object_it_ships():
@@ -46,7 +50,11 @@ def test_guard_catches_compiler_use_of_accumulation_registers(tmp_path):
     # (1) a compiler-made AGPR access outside any inline-asm block of a mix kernel
     k = re.search(r"^(_ZN5hcamd\S*lz4_compress_kernel_mixILi1E\S*):", text, re.M)
     at = text.index("\n", k.end()) + 1
+    kp = re.search(r"^(_ZN5hcamd\S*lz4_compress_kernel_pairILi1E\S*):", text, re.M)
+    vp = re.search(re.escape(kp.group(1)) + r"\.num_vgpr, (\d+)", text).group(1)
     for doctored, what in (
+        # a pair kernel that no longer fits twice on a SIMD
+        (text.replace(kp.group(1) + ".num_vgpr, " + vp, kp.group(1) + ".num_vgpr, 236"), "two waves per SIMD"),
         (text[:at] + "\tv_accvgpr_read_b32 v1, a7\n" + text[at:], "uses an accumulation register"),
         (text[:at] + "\tglobal_load_dword a[3], v1, s[2:3]\n" + text[at:], "uses an accumulation register"),
         (text.replace(k.group(1) + ".num_agpr, 24", k.group(1) + ".num_agpr, 32"), "num_agpr 32"),

@@ -1,7 +1,6 @@
 """The batched calls inside a HIP graph: compress + decompress of a batch captured from a stream once and
-replayed -- nothing in the calls synchronises, allocates or reads the host (the LZ4 encoder's prefetch
-companion, which lives on a stream of the library's own, is left out of a capture: lz4_kernels.hip,
-prefetch_side_begin).  Every replay must give the sizes and the round trip of the plain calls."""
+replayed -- nothing in the calls synchronises, allocates or reads the host, and every kernel of a call is
+launched on the caller's stream.  Every replay must give the sizes and the round trip of the plain calls."""
 import importlib
 import os
 import sys

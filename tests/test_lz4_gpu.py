@@ -649,15 +649,15 @@ def test_match_at_lane_63_with_the_next_window_beyond_it(hc, oracle, reflib, cud
     compare_with_reference(reflib, "lane 63", _reference_agrees(hc, cases, dtype, 65536, [_want(oracle, c, es, 65536) for c in cases], tname))
 
 
-def test_two_host_threads_on_two_streams_share_the_prefetch_side_stream(hc, cuda):
-    """The mix kernel's prefetch companion runs on one side stream per device, bracketed by two shared events
-    (lz4_kernels.hip, prefetch_side_begin/_end): two host threads compressing on two streams at once must each
-    get the bytes a lone call gets, and every call's arrays must be free to reuse once its own stream is
-    synchronised."""
+def test_two_host_threads_on_two_streams(hc, cuda):
+    """The library keeps no state of its own between or across calls (round 4's prefetch companion, with its
+    side stream, events and lock, is gone): two host threads compressing on two streams at once must each get
+    the bytes a lone call gets, and every call's arrays must be free to reuse once its own stream is
+    synchronised.  (6000 chunks: the pair shape of the encoder, lz4_mix.hiph.)"""
     import threading
     import torch
     import bench
-    n = 6000   # (more than twice what the chip holds at once: the companion is launched)
+    n = 6000
     data = [bench.gen_data("uniform", 0, n, cuda, 0x5EED0100 + i) for i in range(2)]
     jobs = [bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(hc.hipcompType.CHAR), d) for d in data]
     alone = []

@@ -247,6 +247,12 @@ Lz4PairShape lz4_compress_shape_pair(uint32_t ht_size, size_t batch, bool tagged
   sh.tagged = tagged ? 1u : 0u;
   sh.table_bytes = round_up(ht_size * (tagged ? 3u : 2u), 16u);
   sh.lds_bytes = sh.table_bytes + 64u; // (kPairSyncBytes)
+#ifdef HC_MEASUREMENT_KNOBS
+  // (HIPCOMP_LZ4_PAIR_LDS: more LDS than a pair needs, i.e. fewer pairs per CU -- what the pairs of a CU cost each other)
+  if (const char* e = std::getenv("HIPCOMP_LZ4_PAIR_LDS"))
+    if ((uint32_t)std::atoi(e) > sh.lds_bytes && (uint32_t)std::atoi(e) <= 64u * 1024u)
+      sh.lds_bytes = (uint32_t)std::atoi(e);
+#endif
   uint32_t per_cu = kLdsPerCu / round_up(sh.lds_bytes, kLdsGranule);
   if (per_cu > 8)
     per_cu = 8;

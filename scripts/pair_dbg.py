@@ -43,6 +43,9 @@ for dt in a.dtype.split(","):
             print(f"   {nme:40s} {buf[k]}")
         if buf[11]:
             print(f"   blocks through the tables {buf[11]}; per block and wave: walk {256 * buf[10] / buf[11]:.0f} ticks, of which waiting for the token {256 * buf[8] / buf[11]:.0f} (s_memtime ticks)")
+            w2 = 2 * max(buf[0], 1)
+            print(f"   per walk and wave: {256 * buf[10] / w2:.0f} ticks, of which until the first words {256 * buf[13] / w2:.0f}, the end (decisions, barriers, undo) {256 * buf[12] / w2:.0f}")
+            print(f"   early looks that did not find the token: {buf[14]} of {buf[11]}")
             print(f"   walks by SIMD: wave 0 {list(buf[16:20])}, wave 1 {list(buf[20:24])}")
         sys.stdout.flush()
     del job

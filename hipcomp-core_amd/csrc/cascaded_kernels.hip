@@ -62,6 +62,20 @@ template <> struct UIntOf<8> { typedef uint64_t type; typedef int64_t stype; };
 
 __device__ __forceinline__ uint32_t ru(uint32_t a, uint32_t b) { return (a + b - 1) / b * b; }
 
+// An array of `nbytes` bytes at byte offset pos + rel of a stream of end_words words: 4-byte aligned and inside
+// (reference block_read :712-713) -- in arithmetic that cannot wrap: nbytes comes straight from the stream, and
+// 0xFFFFF000 must not pass for a short array (the 32-bit sum did).
+__device__ __forceinline__ bool array_inside(uint32_t pos, uint32_t rel, uint32_t nbytes, uint32_t end_words)
+{
+  const uint64_t off = (uint64_t)pos + rel;
+  return !(off & 3u) && off / 4u + ((uint64_t)nbytes + 3u) / 4u <= end_words;
+}
+// ... and within the first stage_bytes bytes of its sub-chunk (the staged image)
+__device__ __forceinline__ bool array_staged(uint32_t rel, uint32_t nbytes, uint32_t stage_bytes)
+{
+  return (uint64_t)rel + (((uint64_t)nbytes + 3u) & ~3ull) <= stage_bytes;
+}
+
 // ---------------------------------------------------------------------------
 // The register-blocked layout.  A ROUND is 64 x E consecutive elements of an LDS array, lane t
 // holding elements [t E, (t + 1) E) of it in registers: E = 16 (8 for 8-byte elements), i.e. a
@@ -1155,9 +1169,9 @@ __device__ __forceinline__ int wave_read_array(
     int bp, const uint32_t* stage, ET* dst, uint32_t max_elems, int lane)
 {
   const uint32_t off = pos + rel;
-  if ((off & 3u) || (off + ru(nbytes, 4)) / 4 > end_words)
+  if (!array_inside(pos, rel, nbytes, end_words))
     return -1;
-  if (rel + ru(nbytes, 4) <= STAGE_WORDS * 4)
+  if (array_staged(rel, nbytes, STAGE_WORDS * 4))
     return unpack_array<ET>(stage + rel / 4, nbytes, bp, dst, max_elems, lane);
   return unpack_array<ET>(reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off), nbytes, bp, dst,
                           max_elems, lane);
@@ -1628,7 +1642,7 @@ __device__ __forceinline__ void cascaded_decode_partition4(
       offs_final = ru(offs_final + meta_at((uint32_t)i + 1u), 4u);
     bool staged = true; // the staged image still holds the head of the sub-chunk
     // bounds of an array at byte offset `rel` of the sub-chunk (reference block_read :712-713)
-    auto inside = [&](uint32_t rel, uint32_t nbytes) { return !(((pos + rel) & 3u) || (pos + rel + ru(nbytes, 4)) / 4 > end_w); };
+    auto inside = [&](uint32_t rel, uint32_t nbytes) { return array_inside(pos, rel, nbytes, end_w); };
     // `count` words from HBM to LDS
     auto fetch = [&](uint32_t* dst, uint32_t rel, uint32_t count) {
       const HC_GLOBAL uint32_t* g = reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + pos + rel);
@@ -1641,7 +1655,7 @@ __device__ __forceinline__ void cascaded_decode_partition4(
     {
       const uint32_t rel = msz + offs_final, nbytes = meta_at(1u + (uint32_t)R);
       if (inside(rel, nbytes)) {
-        if (rel + ru(nbytes, 4) <= kStageWords * 4) {
+        if (array_staged(rel, nbytes, kStageWords * 4)) {
           n = unpack_values4((const HC_LDS uint32_t*)(stage + rel / 4), nbytes, bp, (HC_LDS uint8_t*)X, lane);
         } else {
           // outside the staged image: its words (1026 at most are looked at) into X itself, unpacked in
@@ -1712,7 +1726,7 @@ __device__ __forceinline__ void cascaded_decode_partition4(
             // the array's words: in the staged image, or staged now in its place if they fit it
             const uint32_t need = ru(nbytes, 4);
             uint32_t at = ~0u; // word of `stage` the array begins at
-            if (staged && rel + need <= kStageWords * 4) {
+            if (staged && array_staged(rel, nbytes, kStageWords * 4)) {
               at = rel / 4;
             } else if (need <= kStageWords * 4) {
               fetch(stage, rel, need / 4);
@@ -2077,9 +2091,9 @@ __device__ __forceinline__ void cascaded_decode_partition(
         {
           const uint32_t rel = msz + o, nbytes = uniform(meta[l + 1]);
           const uint32_t off = pos + rel;
-          bool good = !((off & 3u) || (off + ru(nbytes, 4)) / 4 > end_w);
+          bool good = array_inside(pos, rel, nbytes, end_w);
           if (good) {
-            if (rel + ru(nbytes, 4) <= kStageWords * 4)
+            if (array_staged(rel, nbytes, kStageWords * 4))
               good = run_starts(static_cast<const uint32_t*>(stage + rel / 4));
             else
               good = run_starts(reinterpret_cast<const HC_GLOBAL uint32_t*>(comp + off));

@@ -602,6 +602,11 @@ hipError_t lz4_launch_compress(
   }
   // (zeroed by a kernel, not hipMemsetAsync: see lz4_launch_decompress)
   lz4_zero_words_kernel<<<dim3(1), dim3(kHeaderWords), 0, stream>>>(header);
+  {
+    const hipError_t zeroed = hipGetLastError();
+    if (zeroed != hipSuccess)
+      return zeroed;
+  }
   if (mode == Lz4Mode::Auto && lists) {
     // every chunk to the shape its data calls for
     // (chunks per workgroup: one per wave while that leaves the chip room, at most 64 -- one list
@@ -630,22 +635,33 @@ hipError_t lz4_launch_decompress(
     size_t* actual_bytes, hipcompStatus_t* statuses, bool write_out,
     hipStream_t stream, void* temp, size_t temp_bytes)
 {
-  // a ticket counter in the caller's temp buffer (4 bytes, 4-byte aligned), zeroed on the stream: the
-  // persistent grid (lz4_decode.hiph); without one, a wave per chunk by position
+  // More chunks than the chip holds waves: a persistent grid that draws its chunks from a ticket counter
+  // (lz4_decode.hiph), else a wave per chunk by position.  The counter is ONE word of the caller's temp buffer,
+  // zeroed on the stream -- a different word for every call of the process (a running call number, modulo the
+  // buffer's words: 6 per chunk by the size contract, i.e. at least 49 152 where tickets are used at all), so
+  // that calls in flight at once on several streams may share one temp buffer, as they may with the reference,
+  // which never touches it (src/lowlevel/LZ4CompressionKernels.hip:224-249; tests/test_lz4_gpu.py:
+  // test_concurrent_decompress_calls_share_one_temp_buffer).
+  static std::atomic<uint32_t> calls{0};
   uint32_t* ticket = nullptr;
-  if (temp != nullptr) {
-    const uintptr_t at = (reinterpret_cast<uintptr_t>(temp) + 3u) & ~uintptr_t(3);
-    if (at + sizeof(uint32_t) <= reinterpret_cast<uintptr_t>(temp) + temp_bytes)
-      ticket = reinterpret_cast<uint32_t*>(at);
-  }
   size_t groups = (batch + kDecompWavesPerBlock - 1) / kDecompWavesPerBlock;
+  const size_t resident = (size_t)num_cus_of_current_device() * (32 / kDecompWavesPerBlock);
+  if (groups > resident && temp != nullptr) {
+    const uintptr_t at = (reinterpret_cast<uintptr_t>(temp) + 3u) & ~uintptr_t(3);
+    const uintptr_t end = reinterpret_cast<uintptr_t>(temp) + temp_bytes;
+    if (at + sizeof(uint32_t) <= end) {
+      const size_t words = (end - at) / sizeof(uint32_t);
+      ticket = reinterpret_cast<uint32_t*>(at) + calls.fetch_add(1, std::memory_order_relaxed) % words;
+    }
+  }
   if (ticket) {
-    // (a kernel, not hipMemsetAsync: captured into a graph behind the compress call's kernels, the memset node
-    // of this ROCm did not keep its place in front of the decode kernel -- tests/test_graph_capture_gpu.py)
+    // (a kernel, not hipMemsetAsync: with the memset, a graph captured from compress + decompress replayed
+    // with wrong bytes in round 4 -- tests/test_graph_capture_gpu.py; with the kernel it does not)
     lz4_zero_words_kernel<<<dim3(1), dim3(1), 0, stream>>>(ticket);
-    const size_t resident = (size_t)num_cus_of_current_device() * (32 / kDecompWavesPerBlock);
-    if (groups > resident)
-      groups = resident;
+    const hipError_t zeroed = hipGetLastError();
+    if (zeroed != hipSuccess)
+      return zeroed;
+    groups = resident;
   }
   const dim3 grid((unsigned)groups);
   const dim3 block(kWave * kDecompWavesPerBlock);

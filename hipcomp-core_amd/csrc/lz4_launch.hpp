@@ -76,9 +76,10 @@ hipError_t lz4_launch_compress(
 size_t lz4_compress_temp_bytes_used(uint32_t ht_size, size_t batch);
 
 // write_out == false: parse-only pass that reports sizes.
-// `temp` / `temp_bytes`: the caller's temp buffer (hipcompBatchedLZ4DecompressGetTempSize bytes by contract; 4
-// of them are used: a chunk ticket counter, zeroed on the stream); nullptr / too small: accepted, one wave
-// per chunk by its position in the grid.
+// `temp` / `temp_bytes`: the caller's temp buffer (hipcompBatchedLZ4DecompressGetTempSize bytes by contract).  A call
+// with more chunks than the chip holds waves uses ONE 4-byte word of it as its chunk ticket counter (zeroed on the
+// stream), a different word for every call of the process -- calls in flight at once may share the buffer; nullptr /
+// too small: accepted, one wave per chunk by its position in the grid.  Returns the error of a launch that failed.
 hipError_t lz4_launch_decompress(
     const uint8_t* const* comp_ptrs, const size_t* comp_bytes,
     const size_t* out_caps, size_t batch, uint8_t* const* out_ptrs,

@@ -71,6 +71,9 @@ hipcompStatus_t hipcompBatchedLZ4DecompressGetTempSize(
 
 /* Decompress.  device_actual_uncompressed_bytes and device_statuses may be
  * NULL.  An undecodable chunk gets size 0 and hipcompErrorCannotDecompress.
+ * device_temp_ptr: as in the reference a valid device pointer; one 4-byte word
+ * of it (another one for every call) may be written while the call runs, so
+ * calls in flight at once may share one buffer.
  * (reference LZ4Batch.cpp:89-125) */
 hipcompStatus_t hipcompBatchedLZ4DecompressAsync(
     const void* const* device_compressed_ptrs,

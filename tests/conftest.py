@@ -35,7 +35,7 @@ def reflib(hc):
     return hc.HipcompLibrary(O.REF_LIB_PATH)
 
 
-LZ4_SHAPES = ("auto", "mix", "far", "fars", "farw")
+LZ4_SHAPES = ("auto", "mix", "pair", "far", "fars", "farw")
 
 
 def force_lz4_shape(hc, monkeypatch, shape):
@@ -44,17 +44,22 @@ def force_lz4_shape(hc, monkeypatch, shape):
     kernel sends it) for "auto", the knobs build (lib/libhipcomp_knobs.so: the same sources and the
     same device code -- tests/test_build_guards_cpu.py -- with HIPCOMP_LZ4_SHAPE read at every call)
     for a forced shape."""
+    monkeypatch.delenv("HIPCOMP_LZ4_PAIR", raising=False)
     if shape == "auto":
         monkeypatch.delenv("HIPCOMP_LZ4_SHAPE", raising=False)
         return
-    monkeypatch.setenv("HIPCOMP_LZ4_SHAPE", shape)
+    # "pair": the LDS shape as two waves per chunk (lz4_mix.hiph, lz4_compress_kernel_pair) whatever the size of
+    # the batch -- the product takes it from 1536 chunks of 32 .. 64 KiB on; "mix": four lone waves per workgroup
+    monkeypatch.setenv("HIPCOMP_LZ4_PAIR", "1" if shape == "pair" else "0")
+    monkeypatch.setenv("HIPCOMP_LZ4_SHAPE", "mix" if shape == "pair" else shape)
     monkeypatch.setattr(hc.batch, "default_library", hc.knobs_library)
 
 
 @pytest.fixture(params=LZ4_SHAPES)
 def lz4_shape(request, monkeypatch, hc):
     """Every launch shape of the LZ4 encoder in turn: "auto" (the product library) lets the routing
-    kernel send every chunk to the shape its data calls for, the others (the knobs build, see
+    kernel send every chunk to the shape its data calls for, the others ("pair": the LDS shape with two
+    waves per chunk; the knobs build, see
     force_lz4_shape) force one for all chunks -- also on data it would never be picked for (the far
     shapes on chunks without a match, the LDS shape and the wide form on text).  The compressed
     bytes must not depend on it."""

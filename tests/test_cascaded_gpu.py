@@ -118,6 +118,32 @@ def test_decoder_error_paths_match_oracle(hc, oracle, cuda):
     assert sizes == [oracle.cascaded_decompressed_size(s) for s in streams]
 
 
+@pytest.mark.parametrize("t", [5, 3, 7])
+def test_hostile_array_lengths_do_not_wrap_the_bounds_test(hc, oracle, cuda, t):
+    """A sub-chunk's array lengths come straight from the stream.  0xFFFFF000 and its like made the 32-bit sum
+    `offset + roundUp4(length)` of the reference's bounds test (block_read :712-713) wrap and pass, and the
+    decoder then read up to 4 KiB past the compressed buffer (round 4's advisor).  Every such stream is refused;
+    the chunks beside it in the batch decode as ever."""
+    dt = NP[t]
+    data = _sorted_column(11, 4096).astype(dt).tobytes()
+    good, _ = oracle.cascaded_compress(data, t, 2, 1, 1)
+    assert good[0] == 2 and good[1] == 1 and good[2] == 1
+    streams = [good]
+    for word in (1, 2, 3):                      # rle_bytes of layer 0 and 1, final_bytes of the first sub-chunk
+        for hostile in (0xFFFFF000, 0xFFFFFFFC, 0xFFFFFFFF, 0x80000000, 0xFFFFF000 + 8):
+            bad = bytearray(good)
+            at = 8 + 4 * word
+            bad[at:at + 4] = hostile.to_bytes(4, "little")
+            streams.append(bytes(bad))
+    streams.append(good)
+    comp = hc.batch.from_host_chunks(streams, "cuda:0")
+    dec, actual, statuses = hc.batch.Codec("Cascaded").decompress(comp, len(data))
+    st, ac = statuses.cpu().tolist(), actual.cpu().tolist()
+    assert st[0] == 0 and st[-1] == 0 and dec.chunk_bytes(0, ac[0]) == data and dec.chunk_bytes(len(streams) - 1, ac[-1]) == data
+    for i in range(1, len(streams) - 1):
+        assert st[i] == hc.hipcompStatus.ErrorCannotDecompress and ac[i] == 0, (i, st[i], ac[i])
+
+
 def test_host_side_errors(hc, cuda):
     import torch
     src = hc.batch.from_host_chunks([bytes(400)], "cuda:0")

@@ -35,7 +35,7 @@ def _check(rec, got, what):
         assert got == base64.b64decode(rec["b64"]), what
 
 
-@pytest.mark.parametrize("shape", ["auto", "mix", "far", "fars", "farw"])
+@pytest.mark.parametrize("shape", ["auto", "mix", "pair", "far", "fars", "farw"])
 def test_lz4_kernels_reproduce_the_golden_vectors(hc, cuda, monkeypatch, shape):
     import torch
     force_lz4_shape(hc, monkeypatch, shape)

@@ -145,7 +145,7 @@ def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, lz4_s
         assert counts[0] >= 5 * 32                                     # random bytes, the empty chunk, the tiny one: LDS shape
         assert counts[1] + counts[2] + counts[3] >= 30 * 32            # text, the harness's data, runs: far shapes
     else:
-        forced = {"mix": 0, "far": 1, "fars": 2, "farw": 3}[lz4_shape]
+        forced = {"mix": 0, "pair": 0, "far": 1, "fars": 2, "farw": 3}[lz4_shape]
         assert tickets[forced] >= src.n and sum(counts) == 0
     if lz4_shape in ("far", "fars", "farw"):                           # 1536 chunks: device-table waves beside the LDS ones
         assert bool((temp[256 + 16 * src.n:] != 0xAB).any().item())     # hash tables in the temp buffer were written
@@ -694,3 +694,35 @@ def test_two_host_threads_on_two_streams(hc, cuda):
         idx = torch.arange(stride, device=cuda)[None, :] < sizes[:, None]
         assert bool(((A == B) | ~idx).all().item())
         job.verify()
+
+
+def test_concurrent_decompress_calls_share_one_temp_buffer(hc, cuda):
+    """The reference never touches the decompress temp buffer (src/lowlevel/LZ4CompressionKernels.hip:224-249), so its
+    callers may hand ONE buffer to calls in flight on several streams.  Here a large call keeps its chunk ticket
+    counter in one word of it -- a different word per call (lz4_kernels.hip, lz4_launch_decompress): two batches
+    decompressed at once on two streams through the same temp buffer, several times over, must both come back whole
+    (a shared counter would leave chunks undecoded or decode them twice)."""
+    import torch
+    import bench
+    n = 12000   # (more chunks than the chip holds waves: the persistent grid with tickets)
+    kinds = ("harness", "uniform")
+    data = [bench.gen_data(k, 0, n, cuda, 0x5EED0200 + i) for i, k in enumerate(kinds)]
+    jobs = [bench.CodecJob(hc, hc.default_library(), "LZ4", hc.LZ4Opts(hc.hipcompType.CHAR), d) for d in data]
+    for job in jobs:
+        job.compress()
+    torch.cuda.synchronize()
+    shared = jobs[0].dtemp
+    jobs[1].dtemp = shared
+    streams = [torch.cuda.Stream(device=cuda) for _ in jobs]
+    for rep in range(4):
+        for job in jobs:
+            job.out.data.zero_()
+            job.actual.zero_()
+            job.statuses.fill_(-1)
+        torch.cuda.synchronize()
+        for job, st in zip(jobs, streams):
+            with torch.cuda.stream(st):
+                job.decompress()
+        torch.cuda.synchronize()
+        for job in jobs:
+            job.verify()

@@ -438,7 +438,8 @@ def profiled(label: str, phase: str):
     """What the committed rocprofv3 passes say about one bench row's kernel (profiles/rNN_rows.json,
     written by scripts/collect_profiles.sh + scripts/profile_rows.py): average duration from
     --kernel-trace --stats, HBM-side bytes per launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes
-    (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE).  None when
+    (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE; not doubled for
+    the kernels whose reads are narrow gathers -- scripts/profile_rows.py says which and why).  None when
     there is no pass for this row OR the passes were taken on another build of the kernels (the file
     records the sha256 of the device sources it was measured on)."""
     global PROFILED_ROWS
@@ -600,7 +601,7 @@ def main():
             "decompress_GBps": n_bytes / (td_avg * 1e-3) / 1e9,
             "compress_ms": tc_avg, "decompress_ms": td_avg,
             "roofline": dict(roofline_of(f"lz4/{args.dist}/{args.dtype}/{args.chunks}", "compress", algo, tc_avg),
-                             kernel="lz4_compress_kernel_mix" if args.dist == "uniform" else "lz4_compress_kernel_far",
+                             kernel="lz4_compress_kernel_pair" if args.dist == "uniform" else "lz4_compress_kernel_far",
                              decompress_achieved=algo / (td_avg * 1e-3) / 1e9,
                              decompress_frac=algo / (td_avg * 1e-3) / 1e9 / HBM_PEAK_GBS),
         }

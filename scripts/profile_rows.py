@@ -6,13 +6,20 @@ total time whose name holds the phase), its average duration over the dispatches
 with per-chunk routing a compress call launches one kernel per class and the ones whose list is
 empty leave at once: dispatches shorter than a tenth of the longest are left out, here and in the
 PMC averages -- and the HBM-side bytes per launch from the separate --pmc FETCH_SIZE / WRITE_SIZE
-passes: traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE tallies 128-byte requests
-at 64 bytes for wide streaming reads, MI355X_MICROARCH.md; narrower gathers are not calibrated, so the
-read side is an upper estimate).  The file records the sha256 of the device sources (bench.kernel_source_id):
-bench.py ignores it for any other build."""
+passes, both ways: traffic_x2 = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE tallies 128-byte
+requests at 64 bytes for wide streaming reads, MI355X_MICROARCH.md) and traffic_raw = (FETCH_SIZE +
+WRITE_SIZE) x 1024.  The doubling is calibrated on streaming reads; the kernels whose reads are gathers of 2
+to 16 bytes anywhere in a table or a chunk -- the LZ4 far kernels and the Snappy encoder -- ask for 64-byte
+requests, which FETCH_SIZE counts as they are (profiles/r04_cache_counters.txt), so
+traffic_bytes_per_launch -- what bench.py reports -- is the raw figure for those (GATHER_KERNELS) and the
+doubled one for all others; "fetch_correction" says which.  The file records the sha256 of the device sources
+(bench.kernel_source_id): bench.py ignores it for any other build."""
 import csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+GATHER_KERNELS = ("lz4_compress_kernel_far", "snappy_compress_kernel")
 
 
 def short(name):
@@ -62,8 +69,13 @@ def main():
             e = {"kernel": kn, "avg_ms": sum(w) / len(w) / 1e6, "dispatches": len(w), "dispatches_left_out": len(dur[kn]) - len(w)}
             if kn in fetch and kn in write:
                 fw, ww = working(fetch[kn]), working(write[kn])
-                e.update({"FETCH_SIZE_KiB": sum(fw) / len(fw), "WRITE_SIZE_KiB": sum(ww) / len(ww),
-                          "traffic_bytes_per_launch": (2 * sum(fw) / len(fw) + sum(ww) / len(ww)) * 1024})
+                f_kib, w_kib = sum(fw) / len(fw), sum(ww) / len(ww)
+                gather = any(kn.startswith(g) for g in GATHER_KERNELS)
+                e.update({"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib,
+                          "traffic_raw_bytes_per_launch": (f_kib + w_kib) * 1024,
+                          "traffic_x2_bytes_per_launch": (2 * f_kib + w_kib) * 1024,
+                          "fetch_correction": "raw" if gather else "x2",
+                          "traffic_bytes_per_launch": ((1 if gather else 2) * f_kib + w_kib) * 1024})
             ent[phase] = e
         table["rows"][row] = ent
     json.dump(table, open(dst, "w"), indent=1)

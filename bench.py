@@ -332,9 +332,24 @@ def measure_row(hc, lib, codec: str, opts, data, label: dict, key: str, reps: in
                 "hbm_frac_decompress": (nb + cb) / (min(td) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "roofline": {"compress": roofline_of(key, "compress", nb + cb, min(tc)),
                              "decompress": roofline_of(key, "decompress", nb + cb, min(td))}})
+    if REF_LIB is not None:
+        # --ref: the reference's own kernels (oracle/_ref) on the same GPU and data, outside every timed region
+        rjob = CodecJob(hc, REF_LIB, codec, opts, data)
+        rjob.compress(); rjob.decompress(); torch.cuda.synchronize()
+        rtc, rtd = time_phases(rjob, 2)
+        row["reference_gpu"] = {
+            "compress_ms": min(rtc), "decompress_ms": min(rtd),
+            "compress_GBps": nb / (min(rtc) * 1e-3) / 1e9, "decompress_GBps": nb / (min(rtd) * 1e-3) / 1e9,
+            "compressed_sizes_identical": bool(torch.equal(rjob.comp.sizes, job.comp.sizes)),
+            "speedup_compress": min(rtc) / min(tc), "speedup_decompress": min(rtd) / min(td),
+        }
+        del rjob
     del job
     torch.cuda.empty_cache()
     return row
+
+
+REF_LIB = None   # (--ref: hc.HipcompLibrary of oracle/_ref/libhipcomp_ref.so, set in main)
 
 
 def gen_mixed(n_chunks: int, device):
@@ -347,24 +362,43 @@ def gen_mixed(n_chunks: int, device):
     return torch.stack([a, b], dim=1).reshape(-1).contiguous()
 
 
+# The LZ4 routing kernel (lz4_far.hiph:lz4_route_kernel) looks at FOUR pieces of 256 bytes of a 64 KiB chunk, at
+# 1/8, 3/8, 5/8 and 7/8 of it; its first stretch at the first 128 bytes of the first and the third piece, and a
+# chunk without a sign of a repeat there is looked at no further.
+ROUTE_PIECES = tuple((2 * k + 1) * (CHUNK // 8) for k in range(4))   # 8192, 24576, 40960, 57344
+ROUTE_PIECE_BYTES = 256
+
+
 def gen_misrouted(kind: str, n_chunks: int, device):
-    """Chunks whose MIDDLE -- the 1 KiB the LZ4 routing kernel looks at (lz4_far.hiph:lz4_route_kernel) --
-    misrepresents them: "text_random_middle" = TPC-H-like text with 1.5 KiB of random bytes in the middle
-    (routed to the LDS shape, made for data without matches, although the chunk compresses);
-    "random_text_middle" = random bytes with 1.5 KiB of text in the middle (routed to the sparse far
-    class although nothing else in the chunk matches).  The bytes never depend on the routing; these rows
-    put a number on what a wrong guess costs."""
+    """Chunks that misrepresent themselves exactly where the routing kernel looks (adversarial to the sampler as it
+    is: round 4's rows still corrupted the middle KiB, which the sampler no longer reads):
+      "text_random_samples"  TPC-H-like text with random bytes in the four sampled pieces (+ 8 bytes in front: the
+                             sample looks back that far) -- routed to the LDS shape, made for data without matches,
+                             although 98.4 % of the chunk compresses;
+      "random_text_samples"  random bytes with text in the four pieces -- routed to the sparse far class although
+                             nothing else in the chunk matches;
+      "text_random_first"    text with random bytes only where the sampler's FIRST stretch looks (2 x 128 bytes):
+                             the early exit takes the chunk for data without matches.
+    The bytes never depend on the routing; these rows put a number on what a wrong guess costs."""
     import torch
     text = torch.from_numpy(gen_text(n_chunks * CHUNK)).to(device).view(n_chunks, CHUNK)
     rnd = gen_data("uniform", 0, n_chunks, device, 0x5EED0007).view(torch.uint8).view(n_chunks, CHUNK)
-    lo, hi = 32000, 33536
-    if kind == "text_random_middle":
-        out = text.clone()
-        out[:, lo:hi] = rnd[:, lo:hi]
+    if kind == "text_random_first":
+        spans = [(ROUTE_PIECES[0] - 8, ROUTE_PIECES[0] + 128 + 4), (ROUTE_PIECES[2] - 8, ROUTE_PIECES[2] + 128 + 4)]
     else:
-        out = rnd.clone()
-        out[:, lo:hi] = text[:, lo:hi]
+        spans = [(p - 8, p + ROUTE_PIECE_BYTES + 4) for p in ROUTE_PIECES]
+    if kind in ("text_random_samples", "text_random_first"):
+        out, other = text.clone(), rnd
+    elif kind == "random_text_samples":
+        out, other = rnd.clone(), text
+    else:
+        raise ValueError(kind)
+    for lo, hi in spans:
+        out[:, lo:hi] = other[:, lo:hi]
     return out.reshape(-1).contiguous()
+
+
+MISROUTED_KINDS = ("text_random_samples", "random_text_samples", "text_random_first")
 
 
 def measure_hlif(hc, data, reps: int = 2):
@@ -549,6 +583,11 @@ def main():
 
     hc = importlib.import_module("hipcomp-core_amd")
     lib = hc.default_library()
+    if args.ref:
+        from oracle import oracle as O
+        if os.path.exists(O.REF_LIB_PATH):
+            global REF_LIB
+            REF_LIB = hc.HipcompLibrary(O.REF_LIB_PATH)
     dtype = hc.hipcompType.CHAR if args.dtype == "char" else hc.hipcompType.INT
     opts = hc.LZ4Opts(dtype)
 
@@ -678,11 +717,12 @@ def main():
                                      "data_type": "CHAR", "note": "a small batch"}, f"lz4/{dn}/char/1000", reps=5))
             del d
         # what a wrong guess of the routing kernel costs (it looks at 1 KiB from the middle of a chunk)
-        for kind in ("text_random_middle", "random_text_middle"):
+        for kind in MISROUTED_KINDS:
             d = gen_misrouted(kind, 16384, dev)
             rows.append(measure_row(hc, lib, "LZ4", hc.LZ4Opts(hc.hipcompType.CHAR), d,
                                     {"codec": "LZ4", "distribution": "misrouted: " + kind, "data_type": "CHAR",
-                                     "note": "the 1.5 KiB around the routing sample misrepresent the chunk"},
+                                     "note": "exactly the bytes the routing kernel samples (4 x 256 of 65 536; "
+                                             "'first': 2 x 128) misrepresent the chunk: what a wrong guess costs"},
                                     f"lz4/misrouted_{kind}/char/16384", reps=3))
             del d
         tchunks = args.text_chunks

@@ -117,14 +117,14 @@ namespace {
 
 typedef void (*MixKernel)(
     const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t, uint32_t,
-    uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint32_t*, Lz4Placement);
+    uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint32_t*, Lz4Placement, uint32_t);
 typedef void (*FarKernel)(const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint16_t*,
                           uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, const uint32_t*,
-                          const uint32_t*, Lz4Placement);
+                          const uint32_t*, Lz4Placement, uint32_t*, uint32_t*);
 
 typedef void (*PairKernel)(
     const uint8_t* const*, const size_t*, uint8_t* const*, size_t*, uint32_t, uint32_t, uint32_t,
-    uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint32_t*, Lz4Placement);
+    uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint32_t*, Lz4Placement, uint32_t);
 
 PairKernel pair_kernel_for(int elem_size)
 {
@@ -519,7 +519,7 @@ size_t lz4_compress_temp_bytes_used(uint32_t ht_size, size_t batch)
 {
   // header, the four class lists, alignment, one table per chunk but no more than the chip holds waves
   const size_t tables = batch < 8192 ? batch : 8192;
-  return 4 + kHeaderWords * sizeof(uint32_t) + kNumClasses * batch * sizeof(uint32_t) + 16
+  return 4 + kHeaderWords * sizeof(uint32_t) + (kNumClasses + 1) * batch * sizeof(uint32_t) + 16
          + tables * (size_t)(ht_size < 8 ? 8 : ht_size) * sizeof(uint16_t);
 }
 
@@ -535,6 +535,7 @@ hipError_t lz4_launch_compress(
   // as much of that as the (contract-sized) buffer holds
   uint32_t* header = nullptr;
   uint32_t* lists = nullptr;
+  uint32_t* retry_list = nullptr;
   uint16_t* far_tables = nullptr;
   size_t far_capacity = 0;
   if (temp != nullptr) {
@@ -546,6 +547,11 @@ hipError_t lz4_launch_compress(
       if (at + kNumClasses * batch * sizeof(uint32_t) <= end) {
         lists = reinterpret_cast<uint32_t*>(at);
         at += kNumClasses * batch * sizeof(uint32_t);
+        // (a fifth list: the chunks the far kernels give back to the LDS shape, lz4_common.hiph give_away)
+        if (at + batch * sizeof(uint32_t) <= end) {
+          retry_list = reinterpret_cast<uint32_t*>(at);
+          at += batch * sizeof(uint32_t);
+        }
       }
       const uintptr_t tables = (at + 15u) & ~uintptr_t(15);
       if (tables < end) {
@@ -569,8 +575,10 @@ hipError_t lz4_launch_compress(
       per_ticket *= 2;
     return per_ticket;
   };
-  auto launch_mix = [&](const uint32_t* count, const uint32_t* list) {
-    uint32_t* ticket = header ? header + kClassMix : nullptr;
+  // (`ticket_word`: the header's word that is this launch's ticket counter; give: its waves may hand chunks
+  // that open like data that compresses on to the sparse class, whose kernel runs behind them)
+  auto launch_mix = [&](const uint32_t* count, const uint32_t* list, uint32_t ticket_word, bool give) {
+    uint32_t* ticket = header ? header + ticket_word : nullptr;
     // ticket == nullptr: no persistent workgroups, one chunk per wave
     const dim3 grid(ticket ? mix.groups : (unsigned)((batch + mix.waves() - 1) / mix.waves()));
     const size_t resident = pair_mode != 0 ? (size_t)pair.groups : (size_t)mix.groups * mix.waves(); // chunks in flight
@@ -578,11 +586,11 @@ hipError_t lz4_launch_compress(
     if (pair_mode != 0)
       pair_kernel_for(elem_size)<<<dim3(ticket ? pair.groups : (unsigned)batch), dim3(2 * kWave), pair.lds_bytes, stream>>>(
           in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, pair.tagged, pair.table_bytes,
-          (uint32_t)batch, ticket, per_ticket, count, list, place);
+          (uint32_t)batch, ticket, per_ticket, count, list, place, give ? 1u : 0u);
     else
     mix_kernel_for(elem_size)<<<grid, dim3(mix.waves() * kWave), mix.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
-        (uint32_t)batch, ticket, per_ticket, count, list, place);
+        (uint32_t)batch, ticket, per_ticket, count, list, place, give ? 1u : 0u);
   };
   auto launch_far = [&](uint32_t cls, const uint32_t* counts, const uint32_t* all_lists) -> bool {
     const FarGeometry g = far_geometry(ht_size, cls, batch, far_tables ? far_capacity : 0);
@@ -591,13 +599,14 @@ hipError_t lz4_launch_compress(
     far_kernel_for(elem_size, cls)<<<dim3(g.groups), dim3(g.waves() * kWave), g.lds_bytes, stream>>>(
         in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, far_tables, g.near, g.slots,
         far_span(cls), (uint32_t)batch, header + cls,
-        chunks_per_ticket((size_t)g.groups * g.waves()), cls, counts, all_lists, place);
+        chunks_per_ticket((size_t)g.groups * g.waves()), cls, counts, all_lists, place,
+        counts && retry_list ? header + kHeaderRetryCount : nullptr, counts ? retry_list : nullptr);
     return true;
   };
   if (!header) { // (a temp buffer too small for a ticket counter)
     if (place.slots) // (one slot per RESIDENT wave: needs the persistent grids)
       return hipErrorInvalidValue;
-    launch_mix(nullptr, nullptr);
+    launch_mix(nullptr, nullptr, kClassMix, false);
     return hipSuccess;
   }
   // (zeroed by a kernel, not hipMemsetAsync: see lz4_launch_decompress)
@@ -616,16 +625,19 @@ hipError_t lz4_launch_compress(
       per_group *= 2;
     lz4_route_kernel<<<dim3((unsigned)((batch + per_group - 1) / per_group)), dim3(kRouteWaves * kWave), 0, stream>>>(
         in_ptrs, in_bytes, (uint32_t)batch, per_group, header, lists);
-    launch_mix(header + 4 + kClassMix, lists + kClassMix * batch);
+    launch_mix(header + 4 + kClassMix, lists + kClassMix * batch, kClassMix, true);
     for (uint32_t cls = kClassDense; cls <= kClassWide; ++cls)
       if (!launch_far(cls, header + 4, lists))
         return hipErrorInvalidValue; // (cannot happen: the LDS-table waves need nothing but the header)
+    // what the far kernels gave back (chunks that open without a match): once more the LDS shape, which keeps them
+    if (retry_list)
+      launch_mix(header + kHeaderRetryCount, retry_list, kHeaderRetryTicket, false);
     return hipSuccess;
   }
   const uint32_t forced = mode == Lz4Mode::Far ? kClassDense : mode == Lz4Mode::FarSparse ? kClassSparse
                           : mode == Lz4Mode::FarWide ? kClassWide : kClassMix;
   if (forced == kClassMix || !launch_far(forced, nullptr, nullptr))
-    launch_mix(nullptr, nullptr);
+    launch_mix(nullptr, nullptr, kClassMix, false);
   return hipSuccess;
 }
 

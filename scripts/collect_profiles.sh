@@ -22,7 +22,7 @@ if [ $PART = headline ] || [ $PART = all ]; then
   tail -c 900 $O/${R}_bench_under_rocprof.json.log
 fi
 if [ $PART = rows ] || [ $PART = all ]; then
-  ROWS=${ROWS:-"lz4/uniform/char/100000 lz4/uniform/int/100000 lz4/harness/char/100000 lz4/harness/int/100000 lz4/runs/char/100000 lz4/runs/int/100000 lz4/mixed/char/100000 lz4/misrouted_text_random_middle/char/16384 lz4/misrouted_random_text_middle/char/16384 lz4/text/char/65536 lz4/harness/char/1000 lz4/text/char/1000 snappy/text/65536 cascaded/sorted/100000"}
+  ROWS=${ROWS:-"lz4/uniform/char/100000 lz4/uniform/int/100000 lz4/harness/char/100000 lz4/harness/int/100000 lz4/runs/char/100000 lz4/runs/int/100000 lz4/mixed/char/100000 lz4/misrouted_text_random_samples/char/16384 lz4/misrouted_random_text_samples/char/16384 lz4/misrouted_text_random_first/char/16384 lz4/text/char/65536 lz4/harness/char/1000 lz4/text/char/1000 snappy/text/65536 cascaded/sorted/100000"}
   PARTNAME=${PARTNAME:-rows}
   SPECS=""
   for ROW in $ROWS; do

@@ -4,9 +4,9 @@ compressed buffer must be the reference's, size for size and byte for byte (the
 SHA-256 of both is in the assert message), and decode back to the input.
 
 LZ4: uniform / harness / runs (bench.gen_data) and TPC-H-like text x CHAR / INT,
-a batch that mixes chunks without matches and chunks that compress, and two batches whose
-chunks the routing kernel misjudges (bench.gen_misrouted: text with a random middle KiB goes
-through the LDS shape, random bytes with a text middle through the sparse far class).
+a batch that mixes chunks without matches and chunks that compress, and three batches whose
+chunks the routing kernel misjudges (bench.gen_misrouted: text with random bytes exactly where the
+sampler looks goes through the LDS shape, random bytes with text there through the sparse far class).
 Snappy: the config-4 text.  Cascaded: the config-3 sorted columns (the reference's
 output has don't-care bytes there -- SURVEY.md App. C.4 -- so: sizes, both
 decoders on both streams, and byte equality under the oracle's mask on a sample).
@@ -42,7 +42,7 @@ def _data(dist, dev):
         a = bench.gen_data("uniform", 0, CHUNKS // 2, dev, SEEDS["uniform"]).view(CHUNKS // 2, bench.CHUNK)
         b = bench.gen_data("harness", 0, CHUNKS // 2, dev, SEEDS["harness"]).view(CHUNKS // 2, bench.CHUNK)
         return torch.stack([a, b], dim=1).reshape(-1).contiguous()
-    if dist.startswith("misrouted_"):   # the middle KiB (what the routing kernel looks at) misrepresents the chunk
+    if dist.startswith("misrouted_"):   # the bytes the routing kernel looks at misrepresent the chunk
         return bench.gen_misrouted(dist[len("misrouted_"):], min(CHUNKS, 8192), dev)
     return bench.gen_data(dist, 0, CHUNKS, dev, SEEDS[dist])
 
@@ -74,8 +74,8 @@ def _compare_whole_buffers(mine, ref, what):
 
 
 @pytest.mark.parametrize("dtype", ["CHAR", "INT"])
-@pytest.mark.parametrize("dist", ["uniform", "harness", "runs", "text", "mixed", "misrouted_text_random_middle",
-                                  "misrouted_random_text_middle"])
+@pytest.mark.parametrize("dist", ["uniform", "harness", "runs", "text", "mixed", "misrouted_text_random_samples",
+                                  "misrouted_random_text_samples", "misrouted_text_random_first"])
 def test_lz4_bulk_batches_equal_the_reference_build(hc, reflib, cuda, dist, dtype):
     import torch
     import bench

@@ -140,7 +140,12 @@ def test_compressible_batches_take_the_far_shape(hc, oracle, reflib, cuda, lz4_s
     torch.cuda.synchronize()
     tickets, counts, (repeats, looked, near) = _header(temp)
     if lz4_shape == "auto":                                             # (a forced shape skips the routing kernel)
-        assert sum(counts) == src.n and tickets[0] >= counts[0] and sum(tickets[1:]) >= sum(counts[1:])
+        # (a chunk that the LDS shape's wave handed on to the sparse class -- lz4_common.hiph give_away: it opened
+        # like data that compresses -- is on both lists; the chunks the far kernels gave back are counted in word 12)
+        handed_on = sum(counts) - src.n
+        given_back = temp[:64].view(torch.int32).cpu().tolist()[12]
+        assert 0 <= handed_on <= counts[0] and 0 <= given_back <= sum(counts[1:])
+        assert tickets[0] >= counts[0] and sum(tickets[1:]) >= sum(counts[1:])
         assert looked > 0 and repeats * 4 > looked                     # the samples' totals: compressible
         assert counts[0] >= 5 * 32                                     # random bytes, the empty chunk, the tiny one: LDS shape
         assert counts[1] + counts[2] + counts[3] >= 30 * 32            # text, the harness's data, runs: far shapes

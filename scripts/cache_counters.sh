@@ -10,21 +10,29 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 ROWS="lz4/text/char/$N snappy/text/$N lz4/harness/char/$N lz4/runs/char/$N cascaded/sorted/$N"
 P1="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
 P2="TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_TOTAL_ACCESSES_sum"
-P3="TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum"
-P4="TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum TD_TD_BUSY_sum TD_TC_STALL_sum"
+# (the TA block holds two counters per pass: round 4 asked for four in one and the profiler aborted at the first
+# dispatch -- "rocprofiler_create_counter_config ... error code 38: Request exceeds the capabilities of the hardware
+# to collect", gpurun_out/cache_r04/p3.log -- a rejected counter set, not a fault of a kernel)
+P3="TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum"
+P3B="TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
+P4="TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum"
+P4B="TD_TD_BUSY_sum TD_TC_STALL_sum"
 P5="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"
 P6="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum"
 P7="TCC_TAG_STALL_sum TCC_BUSY_sum TCC_CYCLE_sum TCC_EA0_WRREQ_DRAM_sum GRBM_GUI_ACTIVE"
 P8="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
 P9="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 i=0
-for P in "$P1" "$P2" "$P3" "$P4" "$P5" "$P6" "$P7" "$P8" "$P9"; do
+DIRS=""
+for P in "$P1" "$P2" "$P3" "$P3B" "$P4" "$P4B" "$P5" "$P6" "$P7" "$P8" "$P9"; do
   i=$((i+1))
   rm -rf $O/p$i
   echo "pass $i: $P"
-  timeout -k 10 240 rocprofv3 --kernel-trace --output-format csv --pmc $P -d $O/p$i -- python3 scripts/run_rows.py $ROWS --reps 1 > $O/p$i.log 2>&1 || { tail -5 $O/p$i.log; echo "pass $i failed"; }
+  # a pass that fails fails the script, its log kept: a counter set the profiler rejects is to be fixed here
+  timeout -k 10 240 rocprofv3 --kernel-trace --output-format csv --pmc $P -d $O/p$i -- python3 scripts/run_rows.py $ROWS --reps 1 > $O/p$i.log 2>&1 || { tail -8 $O/p$i.log; echo "pass $i ($P) FAILED: see $O/p$i.log"; exit 1; }
+  DIRS="$DIRS $O/p$i"
 done
 grep -h "^lz4\|^snappy\|^cascaded" $O/p1.log || true
-python3 scripts/pmc_table.py $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6 $O/p7 $O/p8 $O/p9 --kernels compress,decompress > $O/${R}_cache_counters_raw.txt
-rm -rf $O/p[0-9]
+python3 scripts/pmc_table.py $DIRS --kernels compress,decompress > $O/${R}_cache_counters_raw.txt
+rm -rf $O/p[0-9] $O/p[0-9][0-9]
 wc -l $O/${R}_cache_counters_raw.txt

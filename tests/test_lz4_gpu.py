@@ -422,6 +422,32 @@ def test_corrupted_streams_decode_like_the_oracle(hc, oracle, cuda):
             assert sizes[i] == (ssize if sst == 0 else 0), (i, "size query")
 
 
+def test_corrupted_chain_streams_decode_like_the_oracle(hc, oracle, cuda):
+    """The decoder's loop with the CHAIN form (lz4_decode.hiph: chunks whose first sequences end in a run without
+    literals -- the harness's kind of data -- take it for good): whole 64 KiB chunks of that kind, damaged in 240
+    ways each, must decode like the oracle -- status, size, bytes -- and so must the size query."""
+    rng = np.random.default_rng(4321)
+    sources = [datagen.harness_like_int32(77, 16384).tobytes(), datagen.harness_like_int32(78, 9000).tobytes()]
+    streams = []
+    for src in sources:
+        good = oracle.lz4_compress(src, 1, 65536)
+        streams += [good] + _corruptions(rng, good, 240)
+    for cap in (65536, 30000):
+        comp = hc.batch.from_host_chunks(streams, "cuda:0")
+        codec = hc.batch.Codec("LZ4")
+        dec, actual, statuses = codec.decompress(comp, cap)
+        st, ac = statuses.cpu().tolist(), actual.cpu().tolist()
+        sizes = codec.get_decompress_size(comp).cpu().tolist()
+        for i, s in enumerate(streams):
+            ost, obytes = oracle.lz4_decompress(s, cap)
+            assert st[i] == ost, (i, cap)
+            assert ac[i] == len(obytes), (i, cap)
+            if ost == 0:
+                assert dec.chunk_bytes(i, ac[i]) == obytes, (i, cap)
+            sst, ssize = oracle.lz4_decompressed_size(s)
+            assert sizes[i] == (ssize if sst == 0 else 0), (i, "size query")
+
+
 def test_decodes_liblz4_streams(hc, cuda):
     """Streams from the system liblz4 (a different, valid encoder) decode."""
     try:

@@ -757,3 +757,36 @@ def test_concurrent_decompress_calls_share_one_temp_buffer(hc, cuda):
         torch.cuda.synchronize()
         for job in jobs:
             job.verify()
+
+
+def test_misjudged_chunks_are_handed_on(hc, oracle, cuda):
+    """The routing kernel looks at 1 KiB of a chunk.  Where exactly that misrepresents the chunk (bench.gen_misrouted)
+    the wave that meets it hands it on early -- the LDS shape to the sparse class, a far wave to the list that one
+    more launch of the LDS shape works through (lz4_common.hiph give_away): the header's counts say so, and the
+    bytes are the oracle's whoever ends up compressing a chunk."""
+    import torch
+    import bench
+    n = 2048
+    for kind, expect in (("text_random_samples", "to the sparse class"), ("random_text_samples", "back to the LDS shape"),
+                         ("text_random_first", "to the sparse class")):
+        data = bench.gen_misrouted(kind, n, cuda)
+        src = hc.batch.from_device_buffer(data, 65536)
+        codec = hc.batch.Codec("LZ4", hc.LZ4Opts(hc.hipcompType.CHAR))
+        dst = hc.batch.alloc_batch(n, codec.max_output_chunk_size(65536), cuda)
+        temp = torch.zeros(codec.compress_temp_size(n, 65536), dtype=torch.uint8, device=cuda)
+        assert codec.compress_async(src, 65536, temp, dst) == 0
+        torch.cuda.synchronize()
+        header = temp[:64].view(torch.int32).cpu().tolist()
+        counts, given_back = header[4:8], header[12]
+        handed_on = sum(counts) - n
+        if expect == "to the sparse class":
+            assert counts[0] >= n * 9 // 10 and handed_on >= n * 9 // 10 and given_back == 0, (kind, counts, given_back)
+        else:
+            assert counts[0] <= n // 10 and given_back >= n * 9 // 10 and handed_on == 0, (kind, counts, given_back)
+        host = data.view(n, 65536)[:4].cpu().numpy()
+        got = dst.to_host_chunks()
+        for i in range(4):
+            assert got[i] == oracle.lz4_compress(host[i].tobytes(), 1, 65536), (kind, i)
+        dec, actual, statuses = codec.decompress(dst, 65536)
+        assert statuses.cpu().tolist() == [0] * n
+        assert torch.equal(dec.data[: n * dec.stride].view(n, dec.stride)[:, :65536].reshape(-1), data)

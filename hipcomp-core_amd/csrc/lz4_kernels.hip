@@ -241,11 +241,11 @@ struct Lz4PairShape
 {
   uint32_t tagged, table_bytes, lds_bytes, groups;
 };
-Lz4PairShape lz4_compress_shape_pair(uint32_t ht_size, size_t batch, bool tagged)
+Lz4PairShape lz4_compress_shape_pair(uint32_t ht_size, size_t batch, uint32_t tagged)
 {
   Lz4PairShape sh;
-  sh.tagged = tagged ? 1u : 0u;
-  sh.table_bytes = round_up(ht_size * (tagged ? 3u : 2u), 16u);
+  sh.tagged = tagged; // (0: no tags, 1: a tag table, 2: tags in the positions)
+  sh.table_bytes = round_up(ht_size * (tagged == 1u ? 3u : 2u), 16u);
   sh.lds_bytes = sh.table_bytes + 64u; // (kPairSyncBytes)
 #ifdef HC_MEASUREMENT_KNOBS
   // (HIPCOMP_LZ4_PAIR_LDS: more LDS than a pair needs, i.e. fewer pairs per CU -- what the pairs of a CU cost each other)
@@ -277,6 +277,16 @@ int lz4_pair_mode(uint32_t ht_size, size_t max_chunk_bytes, size_t batch)
     mode = ht_size >= 8192 ? std::atoi(e) : 0;
 #endif
   return mode;
+}
+
+// (measurement knob HIPCOMP_LZ4_INPOS=0, knobs build only: 4-byte elements with the tag tables of the other widths)
+bool lz4_inpos_wanted()
+{
+#ifdef HC_MEASUREMENT_KNOBS
+  if (const char* e = std::getenv("HIPCOMP_LZ4_INPOS"))
+    return std::atoi(e) != 0;
+#endif
+  return true;
 }
 
 // The library that ships reads nothing from the environment: every chunk goes where the routing
@@ -565,7 +575,20 @@ hipError_t lz4_launch_compress(
     return raised;
   const Lz4CompressShape mix = lz4_compress_shape_mix(ht_size, batch);
   const int pair_mode = lz4_pair_mode(ht_size, max_chunk_bytes, batch);
-  const Lz4PairShape pair = lz4_compress_shape_pair(ht_size, batch, pair_mode == 1);
+  // 4-byte elements in chunks of at most 64 KiB: the tags live in the positions' two spare bits (lz4_common.hiph,
+  // Tables INPOS) -- no tag table, four pairs per CU instead of three, four lone waves all with a filter
+  const bool inpos = elem_size == 4 && max_chunk_bytes <= 65536 && lz4_inpos_wanted();
+  const Lz4PairShape pair = lz4_compress_shape_pair(ht_size, batch, inpos ? 2u : pair_mode == 1 ? 1u : 0u);
+  Lz4CompressShape mix_inpos = mix;
+  if (inpos) { // (every wave's tables are the position table alone)
+    mix_inpos.tagged = 0;
+    mix_inpos.plain = kLz4MaxWavesPerGroup;
+    while (mix_inpos.plain > 1 && (size_t)mix_inpos.plain > batch)
+      --mix_inpos.plain;
+    mix_inpos.lds_bytes = mix_inpos.plain * mix_inpos.stride_plain;
+    set_groups(mix_inpos, batch);
+  }
+  const Lz4CompressShape& mixs = inpos ? mix_inpos : mix;
   // about 16 KiB of input per ticket, but at least 4 tickets per wave so
   // that the last ones even out the load
   auto chunks_per_ticket = [&](size_t all_waves) {
@@ -580,17 +603,17 @@ hipError_t lz4_launch_compress(
   auto launch_mix = [&](const uint32_t* count, const uint32_t* list, uint32_t ticket_word, bool give) {
     uint32_t* ticket = header ? header + ticket_word : nullptr;
     // ticket == nullptr: no persistent workgroups, one chunk per wave
-    const dim3 grid(ticket ? mix.groups : (unsigned)((batch + mix.waves() - 1) / mix.waves()));
-    const size_t resident = pair_mode != 0 ? (size_t)pair.groups : (size_t)mix.groups * mix.waves(); // chunks in flight
+    const dim3 grid(ticket ? mixs.groups : (unsigned)((batch + mixs.waves() - 1) / mixs.waves()));
+    const size_t resident = pair_mode != 0 ? (size_t)pair.groups : (size_t)mixs.groups * mixs.waves(); // chunks in flight
     const uint32_t per_ticket = chunks_per_ticket(resident);
     if (pair_mode != 0)
       pair_kernel_for(elem_size)<<<dim3(ticket ? pair.groups : (unsigned)batch), dim3(2 * kWave), pair.lds_bytes, stream>>>(
           in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, pair.tagged, pair.table_bytes,
           (uint32_t)batch, ticket, per_ticket, count, list, place, give ? 1u : 0u);
     else
-    mix_kernel_for(elem_size)<<<grid, dim3(mix.waves() * kWave), mix.lds_bytes, stream>>>(
-        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mix.tagged, mix.stride_tagged, mix.stride_plain,
-        (uint32_t)batch, ticket, per_ticket, count, list, place, give ? 1u : 0u);
+    mix_kernel_for(elem_size)<<<grid, dim3(mixs.waves() * kWave), mixs.lds_bytes, stream>>>(
+        in_ptrs, in_bytes, out_ptrs, out_bytes, ht_size, mixs.tagged, mixs.stride_tagged, mixs.stride_plain,
+        (uint32_t)batch, ticket, per_ticket, count, list, place, (give ? 1u : 0u) | (inpos ? 2u : 0u));
   };
   auto launch_far = [&](uint32_t cls, const uint32_t* counts, const uint32_t* all_lists) -> bool {
     const FarGeometry g = far_geometry(ht_size, cls, batch, far_tables ? far_capacity : 0);

@@ -267,10 +267,15 @@ Lz4PairShape lz4_compress_shape_pair(uint32_t ht_size, size_t batch, uint32_t ta
 // 0's alone: 32 KiB chunks 415 against 429 GB/s, 64 KiB 466 against 421) and of at most 64 KiB (longer chunks
 // take the walk of one wave), and a batch of two rounds or more of the 3 pairs a CU holds (four lone waves
 // hold a chunk more: 1000 x 64 KiB 268 against 338 GB/s, 1500: 360 against 338).
-int lz4_pair_mode(uint32_t ht_size, size_t max_chunk_bytes, size_t batch)
+// With the tags in the positions (4-byte elements: four pairs per CU, every lone wave with a filter too) pairs win
+// from 32 KiB chunks and a thousand chunks on (sweep_pair3.log: 32 KiB 1 121 against 1 052 GB/s, 16 KiB 891 / 880,
+// 1000 x 64 KiB 677 / 684, 1500: 738 / 692).
+int lz4_pair_mode(uint32_t ht_size, size_t max_chunk_bytes, size_t batch, bool inpos)
 {
-  int mode = ht_size >= 16384 && max_chunk_bytes > 32768 && max_chunk_bytes <= 65536
-                     && batch >= 2u * 3u * (size_t)num_cus_of_current_device()
+  const size_t cus = (size_t)num_cus_of_current_device();
+  int mode = ht_size >= 8192 && max_chunk_bytes <= 65536
+                     && (inpos ? max_chunk_bytes > 16384 && batch >= 4u * cus
+                               : max_chunk_bytes > 32768 && batch >= 2u * 3u * cus)
                  ? 1 : 0;
 #ifdef HC_MEASUREMENT_KNOBS
   if (const char* e = std::getenv("HIPCOMP_LZ4_PAIR"))
@@ -574,10 +579,10 @@ hipError_t lz4_launch_compress(
   if (raised != hipSuccess)
     return raised;
   const Lz4CompressShape mix = lz4_compress_shape_mix(ht_size, batch);
-  const int pair_mode = lz4_pair_mode(ht_size, max_chunk_bytes, batch);
   // 4-byte elements in chunks of at most 64 KiB: the tags live in the positions' two spare bits (lz4_common.hiph,
   // Tables INPOS) -- no tag table, four pairs per CU instead of three, four lone waves all with a filter
   const bool inpos = elem_size == 4 && max_chunk_bytes <= 65536 && lz4_inpos_wanted();
+  const int pair_mode = lz4_pair_mode(ht_size, max_chunk_bytes, batch, inpos);
   const Lz4PairShape pair = lz4_compress_shape_pair(ht_size, batch, inpos ? 2u : pair_mode == 1 ? 1u : 0u);
   Lz4CompressShape mix_inpos = mix;
   if (inpos) { // (every wave's tables are the position table alone)

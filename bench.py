@@ -401,14 +401,22 @@ def gen_misrouted(kind: str, n_chunks: int, device):
 MISROUTED_KINDS = ("text_random_samples", "random_text_samples", "text_random_first")
 
 
-def measure_hlif(hc, data, reps: int = 2):
-    """the high-level LZ4 manager (container = header + offsets / sizes / checksums + chunks,
-    include/hipcomp/hlif.h) over one buffer, beside the batched calls it wraps."""
+def measure_hlif(hc, data, codec: str = "LZ4", reps: int = 2, lib_path=None):
+    """the high-level managers (container = header + offsets / sizes / checksums + chunks,
+    include/hipcomp/hlif.h) over one buffer, beside the batched calls they wrap."""
     import torch
     from ctypes import c_int, c_size_t, c_void_p
-    L = ctypes.CDLL(hc.default_library().path)
+    L = ctypes.CDLL(lib_path or hc.default_library().path)
     h = c_void_p()
-    assert L.hipcompHlifLZ4ManagerCreate(c_size_t(CHUNK), c_int(0), None, ctypes.byref(h)) == 0
+    if codec == "LZ4":
+        assert L.hipcompHlifLZ4ManagerCreate(c_size_t(CHUNK), c_int(0), None, ctypes.byref(h)) == 0
+    elif codec == "Snappy":
+        assert L.hipcompHlifSnappyManagerCreate(c_size_t(CHUNK), None, ctypes.byref(h)) == 0
+    else:
+        class _Opts(ctypes.Structure):
+            _fields_ = [("chunk_size", c_size_t), ("type", c_int), ("num_RLEs", c_int), ("num_deltas", c_int), ("use_bp", c_int)]
+        L.hipcompHlifCascadedManagerCreate.argtypes = [_Opts, c_void_p, c_void_p]
+        assert L.hipcompHlifCascadedManagerCreate(_Opts(CHUNK, int(hc.hipcompType.UINT), 2, 1, 1), None, ctypes.byref(h)) == 0
     n = int(data.numel())
     mx, nc = c_size_t(0), c_size_t(0)
     assert L.hipcompHlifConfigureCompression(h, c_size_t(n), ctypes.byref(mx), ctypes.byref(nc)) == 0
@@ -431,7 +439,8 @@ def measure_hlif(hc, data, reps: int = 2):
         torch.cuda.synchronize(); t0 = time.perf_counter(); comp(); torch.cuda.synchronize(); tcs.append(time.perf_counter() - t0)
         torch.cuda.synchronize(); t0 = time.perf_counter(); dec(); torch.cuda.synchronize(); tds.append(time.perf_counter() - t0)
     L.hipcompHlifManagerDestroy(h)
-    return {"codec": "LZ4 high-level manager (HLIF)", "row": "hlif/lz4/uniform/char", "chunks": nc.value,
+    what = {"LZ4": "uniform/char", "Snappy": "text", "Cascaded": "sorted"}[codec]
+    return {"codec": f"{codec} high-level manager (HLIF)", "row": f"hlif/{codec.lower()}/{what}", "chunks": nc.value,
             "container_bytes": size.value, "ratio": n / max(size.value, 1),
             "compress_GBps": n / min(tcs) / 1e9, "decompress_GBps": n / min(tds) / 1e9,
             "compress_ms": min(tcs) * 1e3, "decompress_ms": min(tds) * 1e3,
@@ -736,6 +745,7 @@ def main():
         if not args.no_cpu:
             srow["cpu_baseline"] = cpu_codec_baseline("Snappy", text_host[: 8192 * CHUNK])
         rows.append(srow)
+        rows.append(measure_hlif(hc, text.view(torch.uint8), "Snappy"))
         del text, text_host
         cols = gen_sorted_columns(vc, dev)
         crow = measure_row(hc, lib, "Cascaded", hc.CascadedOpts(4096, hc.hipcompType.UINT, 2, 1, 1), cols,
@@ -744,6 +754,7 @@ def main():
         if not args.no_cpu:
             crow["cpu_baseline"] = cpu_codec_baseline("Cascaded", cols[: 8192 * CHUNK].cpu().numpy())
         rows.append(crow)
+        rows.append(measure_hlif(hc, cols.view(torch.uint8), "Cascaded"))
         # the option selector (include/hipcomp/cascaded_select.h, an API of this library's own): what it picks
         # for the config-3 columns and for a column that should not be cascaded at all, and the ratio that buys
         for cname, cdata in (("sorted", cols), ("uniform", gen_data("uniform", 0, 16384, dev, seeds["uniform"]).view(torch.uint8))):

@@ -32,6 +32,7 @@
 
 #include "cascaded_launch.hpp"
 #include "lz4_launch.hpp" // num_cus_of_current_device
+#include "placement.hiph"
 #include "wave_utils.hpp"
 
 #include <atomic>
@@ -833,42 +834,22 @@ __device__ __forceinline__ uint32_t write_array4(
   return ob;
 }
 
-// (launch bound: HC_CASC_OCC waves per SIMD; LDS allows 25 one-wave workgroups per CU)
-#ifndef HC_CASC_OCC
-#define HC_CASC_OCC 6
-#endif
+// One partition by the calling wave: in[0 .. in_bytes64) -> out, -> the compressed bytes (0: no input).
+// `my`: the wave's wave_lds_bytes<S>() of LDS.
 template <int S>
-__global__ __launch_bounds__(kWave * kWavesPerBlock, HC_CASC_OCC) void cascaded_compress_kernel(
-    const uint8_t* const* __restrict__ in_ptrs,
-    const size_t* __restrict__ in_bytes_arr,
-    uint8_t* const* __restrict__ out_ptrs,
-    size_t* __restrict__ out_bytes_arr, const size_t batch, const int type_tag,
-    const int R, const int D, const int bp)
+__device__ __forceinline__ uint32_t cascaded_encode_partition(
+    cgptr in, const size_t in_bytes64, gptr out, uint8_t* my, const int type_tag, const int R, const int D, const int bp,
+    const int lane)
 {
   typedef typename UIntOf<S>::type UT;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // kWavesPerBlock * wave_lds_bytes<S>()
-  const int lane = lane_id();
-  // everything that steers the layers is wave-uniform: say so (see uniform())
-  const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
-  const size_t part = (size_t)blockIdx.x * kWavesPerBlock + wave;
-  if (part >= batch)
-    return;
-  uint8_t* my = smem + wave * wave_lds_bytes<S>();
   UT* bufA = reinterpret_cast<UT*>(my);
   uint16_t* cnts = reinterpret_cast<uint16_t*>(my + enc_buf_bytes());                       // (the generic path's layout)
   uint32_t* meta = reinterpret_cast<uint32_t*>(my + enc_buf_bytes() + (CB / S) * 2);
   (void)bufA;
   (void)cnts;
   (void)meta;
-
-  cgptr in = to_global(uniform_ptr(in_ptrs[part]));
-  const size_t in_bytes64 = uniform((uint64_t)in_bytes_arr[part]);
-  gptr out = to_global(uniform_ptr(out_ptrs[part]));
-  if (in == nullptr || in_bytes64 == 0) { // reference :856-860
-    if (lane == 0)
-      out_bytes_arr[part] = 0;
-    return;
-  }
+  if (in == nullptr || in_bytes64 == 0) // reference :856-860
+    return 0;
   const uint32_t in_bytes = (uint32_t)in_bytes64;
   const uint32_t N = in_bytes / S;
   const uint32_t limit = 4u * (2u + (in_bytes + 3u) / 4u); // reference :852-854
@@ -1044,7 +1025,57 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, HC_CASC_OCC) void cascaded_
     const uint32_t h = use ? ((uint32_t)R | ((uint32_t)D << 8) | ((uint32_t)bp << 16)) : 0u;
     reinterpret_cast<HC_GLOBAL uint32_t*>(out)[0] = h | ((uint32_t)type_tag << 24);
     reinterpret_cast<HC_GLOBAL uint32_t*>(out)[1] = N * S;
+  }
+  return total;
+}
+
+// (launch bound: HC_CASC_OCC waves per SIMD; LDS allows 25 one-wave workgroups per CU)
+#ifndef HC_CASC_OCC
+#define HC_CASC_OCC 6
+#endif
+template <int S>
+__global__ __launch_bounds__(kWave * kWavesPerBlock, HC_CASC_OCC) void cascaded_compress_kernel(
+    const uint8_t* const* __restrict__ in_ptrs,
+    const size_t* __restrict__ in_bytes_arr,
+    uint8_t* const* __restrict__ out_ptrs,
+    size_t* __restrict__ out_bytes_arr, const size_t batch, const int type_tag,
+    const int R, const int D, const int bp)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // kWavesPerBlock * wave_lds_bytes<S>()
+  const int lane = lane_id();
+  // everything that steers the layers is wave-uniform: say so (see uniform())
+  const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
+  const size_t part = (size_t)blockIdx.x * kWavesPerBlock + wave;
+  if (part >= batch)
+    return;
+  uint8_t* my = smem + wave * wave_lds_bytes<S>();
+  cgptr in = to_global(uniform_ptr(in_ptrs[part]));
+  const size_t in_bytes64 = uniform((uint64_t)in_bytes_arr[part]);
+  gptr out = to_global(uniform_ptr(out_ptrs[part]));
+  const uint32_t total = cascaded_encode_partition<S>(in, in_bytes64, out, my, type_tag, R, D, bp, lane);
+  if (lane == 0)
     out_bytes_arr[part] = total;
+}
+
+// The same for the high-level manager (placement.hpp; as snappy_compress_placed_kernel): one wave per
+// workgroup, as many workgroups as the device holds, partitions off a ticket counter, each compressed into the
+// wave's slot and moved to its place in the container.
+template <int S>
+__global__ __launch_bounds__(kWave, HC_CASC_OCC) void cascaded_compress_placed_kernel(
+    const uint8_t* const* __restrict__ in_ptrs, const size_t* __restrict__ in_bytes_arr,
+    size_t* __restrict__ out_bytes_arr, const uint32_t batch, const int type_tag, const int R, const int D, const int bp,
+    uint32_t* __restrict__ ticket, const Placement place)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // wave_lds_bytes<S>()
+  const int lane = lane_id();
+  gptr slot = to_global(place.slots + (size_t)blockIdx.x * place.slot_bytes);
+  for (uint32_t part = next_chunk(ticket, lane); part < batch; part = next_chunk(ticket, lane)) {
+    cgptr in = to_global(uniform_ptr(in_ptrs[part]));
+    const size_t in_bytes64 = uniform((uint64_t)in_bytes_arr[part]);
+    const uint32_t total = cascaded_encode_partition<S>(in, in_bytes64, slot, smem, type_tag, R, D, bp, lane);
+    if (lane == 0)
+      out_bytes_arr[part] = total;
+    place_chunk(place, part, slot, total, lane); // (an empty partition takes no room: offset = the cursor as it stands)
   }
 }
 
@@ -2303,6 +2334,59 @@ void cascaded_launch_compress(
                           : elem_size == 4 ? wave_lds_bytes<4>()
                                            : wave_lds_bytes<8>());
   k<<<grid, block, lds, stream>>>(in_ptrs, in_bytes, out_ptrs, out_bytes, batch, type_tag, num_rles, num_deltas, use_bp);
+}
+
+namespace {
+typedef void (*PlacedKernel)(const uint8_t* const*, const size_t*, size_t*, uint32_t, int, int, int, int, uint32_t*, Placement);
+struct PlacedShape { PlacedKernel k; uint32_t lds; int slot; };
+PlacedShape placed_shape(int elem_size)
+{
+  switch (elem_size) {
+  case 1: return {cascaded_compress_placed_kernel<1>, wave_lds_bytes<1>(), 0};
+  case 2: return {cascaded_compress_placed_kernel<2>, wave_lds_bytes<2>(), 1};
+  case 4: return {cascaded_compress_placed_kernel<4>, wave_lds_bytes<4>(), 2};
+  default: return {cascaded_compress_placed_kernel<8>, wave_lds_bytes<8>(), 3};
+  }
+}
+// workgroups of the placed kernel the device holds at once (0: could not be found out)
+unsigned placed_resident(int elem_size)
+{
+  static std::atomic<unsigned> known[4]; // (the same on every device of the process)
+  const PlacedShape sh = placed_shape(elem_size);
+  unsigned r = known[sh.slot].load(std::memory_order_relaxed);
+  if (r == 0) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sh.k, kWave, sh.lds) != hipSuccess || per_cu <= 0) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    r = (unsigned)per_cu * (unsigned)num_cus_of_current_device();
+    known[sh.slot].store(r, std::memory_order_relaxed);
+  }
+  return r;
+}
+} // namespace
+
+size_t cascaded_placement_slots(int elem_size)
+{
+  return placed_resident(elem_size);
+}
+
+hipError_t cascaded_launch_compress_placed(
+    const uint8_t* const* in_ptrs, const size_t* in_bytes, size_t* out_bytes, size_t batch, int type_tag,
+    int elem_size, int num_rles, int num_deltas, int use_bp, uint32_t* ticket, const Placement& place,
+    hipStream_t stream)
+{
+  const unsigned resident = placed_resident(elem_size);
+  if (resident == 0 || batch == 0 || batch >= 0xFFFFFFFFull)
+    return hipErrorInvalidValue;
+  const hipError_t e = hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess)
+    return e;
+  const PlacedShape sh = placed_shape(elem_size);
+  sh.k<<<dim3(batch < resident ? (unsigned)batch : resident), dim3(kWave), sh.lds, stream>>>(
+      in_ptrs, in_bytes, out_bytes, (uint32_t)batch, type_tag, num_rles, num_deltas, use_bp, ticket, place);
+  return hipGetLastError();
 }
 
 // One launch per element width, as the reference (CascadedBatch.hip:387-429) -- but a launch

@@ -7,19 +7,17 @@
 // loop of src/hipcomp_common_deps/hlif_shared.hiph:165-232 (each CTA compresses a chunk into
 // its scratch slot, claims room in the container with an atomic on comp_data_size and copies
 // the chunk there: chunk data in completion order) and :293-345.
-// LZ4 (round 4): the same scheme inside the batched encoders -- a wave compresses into a slot of its own
-// (one per RESIDENT wave, not per chunk), takes the chunk's room in the container with an atomic add on
-// comp_data_size when the size is known, and copies it there; a chunk that ends in one long literal run
-// (data that does not compress) takes its room before that run is written and writes it in place, once
-// (lz4_launch.hpp: Lz4Placement; lz4_common.hiph: reserve_place / place_chunk).  Chunk data in completion
-// order, as in the reference.
-// Snappy, Cascaded: the chunk list goes through the batched kernels a slab of chunks at a time: compress
-// the slab into scratch slots, scan the slab's sizes on top of comp_data_size, copy each chunk to its
-// offset (on a stream of the manager's own, beside the compression of the next slab) -- chunk data in
-// chunk order, the same header, offsets and sizes arrays.  The scratch space is a constant of the
-// manager, as in the reference.
+// Here: the same scheme inside the batched encoders of all three codecs -- a wave compresses into a slot of its
+// own (one per RESIDENT wave, not per chunk), takes the chunk's room in the container with an atomic add on
+// comp_data_size when the size is known, and copies it there (placement.hpp); an LZ4 chunk that ends in one
+// long literal run (data that does not compress) takes its room before that run is written and writes it in
+// place, once (lz4_common.hiph: reserve_place).  Chunk data in completion order, as in the reference.  No
+// stream, event or thread of the manager's own: everything runs on the caller's stream.  The scratch space is a
+// constant of the manager, as in the reference.
+#include "cascaded_launch.hpp"
 #include "host_common.hpp"
 #include "lz4_launch.hpp"
+#include "snappy_launch.hpp"
 #include "wave_utils.hpp"
 
 #include "hipcomp/cascaded.h"
@@ -118,10 +116,10 @@ __global__ void header_kernel(
     *status = hipcompSuccess;
 }
 
-// chunk list of one slab: inputs are slices of the buffer, outputs the scratch slots
+// chunk list of one pass: inputs are slices of the buffer
 __global__ void slab_inputs_kernel(
     const uint8_t* decomp, uint64_t decomp_bytes, uint64_t chunk_bytes, uint64_t first, uint32_t count,
-    uint8_t* slots, uint64_t slot_bytes, const uint8_t** in_ptrs, size_t* in_bytes, uint8_t** out_ptrs)
+    const uint8_t** in_ptrs, size_t* in_bytes)
 {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= count)
@@ -129,56 +127,6 @@ __global__ void slab_inputs_kernel(
   const uint64_t at = (first + i) * chunk_bytes;
   in_ptrs[i] = decomp + at;
   in_bytes[i] = (size_t)(decomp_bytes - at < chunk_bytes ? decomp_bytes - at : chunk_bytes);
-  if (out_ptrs)
-    out_ptrs[i] = slots + (uint64_t)i * slot_bytes;
-}
-
-// one workgroup: offsets of the slab's chunks = running total of the container + exclusive
-// scan of their sizes; the running total moves on
-// (`align`: chunk starts are rounded up to it -- 1 for byte codecs; the Cascaded decoder wants
-// its streams aligned like their elements)
-__global__ __launch_bounds__(kBlock) void slab_place_kernel(
-    uint8_t* container, uint64_t sizes_at, uint64_t offsets_at, uint64_t first, uint32_t count, uint32_t align)
-{
-  __shared__ uint64_t wave_sums[kBlock / 64];
-  CommonHeader* h = reinterpret_cast<CommonHeader*>(container);
-  const uint64_t* sizes = reinterpret_cast<const uint64_t*>(container + sizes_at) + first;
-  uint64_t* offsets = reinterpret_cast<uint64_t*>(container + offsets_at) + first;
-  uint64_t carry = h->comp_data_size;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t i0 = 0; i0 < count; i0 += kBlock) {
-    const uint32_t i = i0 + threadIdx.x;
-    const uint64_t v = i < count ? (sizes[i] + align - 1) / align * align : 0;
-    const uint64_t incl = wave_scan_add_u64(v);
-    if (lane == 63)
-      wave_sums[wave] = incl;
-    __syncthreads();
-    uint64_t before = 0, all = 0;
-    for (int w = 0; w < kBlock / 64; ++w) {
-      before += w < wave ? wave_sums[w] : 0;
-      all += wave_sums[w];
-    }
-    __syncthreads();
-    if (i < count)
-      offsets[i] = carry + before + incl - v;
-    carry += all;
-  }
-  if (threadIdx.x == 0)
-    h->comp_data_size = carry;
-}
-
-// one wave per chunk: scratch slot -> its place in the container
-__global__ __launch_bounds__(kBlock) void slab_gather_kernel(
-    uint8_t* container, uint64_t sizes_at, uint64_t offsets_at, uint64_t data_at, uint64_t first, uint32_t count,
-    const uint8_t* slots, uint64_t slot_bytes)
-{
-  const uint32_t i = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (i >= count)
-    return;
-  const uint64_t size = reinterpret_cast<const uint64_t*>(container + sizes_at)[first + i];
-  const uint64_t off = reinterpret_cast<const uint64_t*>(container + offsets_at)[first + i];
-  wave_copy(to_global(container + data_at + off), to_global(slots + (uint64_t)i * slot_bytes), (uint32_t)size,
-            (int)(threadIdx.x & 63));
 }
 
 // ---- decompression ------------------------------------------------------------------------
@@ -248,7 +196,7 @@ struct Core
   size_t chunk_bytes = 0;
   hipStream_t stream = nullptr;
   size_t slot_bytes = 0;   // hipcompBatched*CompressGetMaxOutputChunkSize(chunk_bytes), 16-byte multiple
-  uint32_t slab = 0;       // chunks per pass
+  uint32_t slab = 0;       // chunks per pass of decompress
   uint8_t format = kLZ4;
   FormatHeader format_header = {};
   uint32_t format_header_bytes = 0;
@@ -259,18 +207,11 @@ struct Core
   uint32_t ht_size = 0;
   // Cascaded
   hipcompBatchedCascadedOpts_t cascaded_opts = {};
+  int cascaded_elem = 4;
 
   uint8_t* scratch = nullptr;
   bool own_scratch = false;
   CommonHeader* header_host = nullptr; // pinned
-  // compress: the placing + gathering of slab i runs on a stream of the manager's own beside the
-  // compression of slab i + 1 (two sets of slots).  The encoders are bound by latency, the gather by
-  // HBM: side by side they cost little more than the encoders alone.  Events: slots[b] filled /
-  // slots[b] free again.  Made on first use; if that fails, everything runs on the one stream.
-  hipStream_t side = nullptr;
-  hipEvent_t filled[2] = {nullptr, nullptr}, emptied[2] = {nullptr, nullptr};
-  bool side_tried = false;
-
   Core(Codec c, size_t chunk, hipStream_t st, int device_id, const char* who) : codec(c), chunk_bytes(chunk), stream(st)
   {
     int dev = -1;
@@ -284,37 +225,6 @@ struct Core
     if (own_scratch)
       (void)hipFree(scratch);
     (void)hipHostFree(header_host);
-    for (int b = 0; b < 2; ++b) {
-      if (filled[b])
-        (void)hipEventDestroy(filled[b]);
-      if (emptied[b])
-        (void)hipEventDestroy(emptied[b]);
-    }
-    if (side)
-      (void)hipStreamDestroy(side);
-  }
-  // the side stream, or nullptr (not available, or `stream` is being captured into a graph)
-  hipStream_t side_stream()
-  {
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    if (!side_tried) {
-      side_tried = true;
-      bool ok = hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess;
-      for (int b = 0; b < 2 && ok; ++b)
-        ok = hipEventCreateWithFlags(&filled[b], hipEventDisableTiming) == hipSuccess
-             && hipEventCreateWithFlags(&emptied[b], hipEventDisableTiming) == hipSuccess;
-      if (!ok) {
-        (void)hipGetLastError();
-        if (side)
-          (void)hipStreamDestroy(side);
-        side = nullptr;
-      }
-    }
-    return side;
   }
   Core(const Core&) = delete;
   Core& operator=(const Core&) = delete;
@@ -322,41 +232,41 @@ struct Core
   void finish_init(size_t max_compressed_chunk)
   {
     slot_bytes = (max_compressed_chunk + 15) & ~size_t(15);
-    // a slab: about 2 GiB of slots, 256 .. 32768 chunks
-    // (every slab ends with the tail of its slowest chunk and a scan + gather of its own: large slabs --
-    // 2 GiB of slots, a small part of this card's 288 GB; the reference's scheme has no slabs at all)
-    const size_t n = (size_t(2048) << 20) / slot_bytes;
-    slab = (uint32_t)(n < 256 ? 256 : (n > 32768 ? 32768 : n));
+    slab = (uint32_t)kPlacedSlab;
   }
 
   Layout layout(size_t n) const { return layout_of(n, format_header_bytes); }
 
-  // scratch: chunk lists of a slab, the slots, and (LZ4) the compress launcher's own temp space
-  // (its header, routing lists and hash tables for a slab: lz4_launch.hpp)
+  // decompress: the chunk lists of a pass (and 64 spare bytes: the LZ4 decoder's ticket counter)
   size_t lists_bytes() const { return (size_t)slab * (8 + 8 + 8 + 8 + 8 + 4) + 64; }
-  size_t lz4_temp_bytes(size_t chunks) const { return codec == LZ4 ? lz4_compress_temp_bytes_used(ht_size, chunks) : 0; }
-  // `sets` sets of slots for `chunks` chunks each
-  size_t scratch_bytes_for(size_t chunks, int sets) const
-  {
-    return lists_bytes() + (size_t)sets * chunks * slot_bytes + 16 + lz4_temp_bytes(chunks);
-  }
-  // what a caller's own scratch buffer must hold: two slabs (compress overlaps the placing of one
-  // with the compression of the next)
-  size_t scratch_bytes() const
-  {
-    const size_t a = scratch_bytes_for(slab, 2), b = codec == LZ4 ? placed_scratch_bytes(kPlacedSlab) : 0;
-    return a > b ? a : b;
-  }
-  // LZ4: the encoders place the chunks themselves (lz4_launch.hpp, Lz4Placement) -- a slot per resident wave
-  // instead of one per chunk, no scan, no gather, no second stream; a pass takes up to kPlacedSlab chunks
-  // (what bounds it is the chunk lists and the launcher's routing lists, 40 bytes per chunk)
+  // compress: the encoders place the chunks themselves (placement.hpp) -- a slot per resident wave, no scan, no
+  // gather, no second stream; a pass takes up to kPlacedSlab chunks (what bounds it is the chunk lists and the
+  // LZ4 launcher's routing lists, 40 bytes per chunk).  Scratch: the pass's input list, 64 spare bytes (the
+  // Snappy / Cascaded kernels' ticket counter), the slots, and the LZ4 launcher's own temp space (its header,
+  // routing lists and hash tables: lz4_launch.hpp).
   static constexpr size_t kPlacedSlab = 262144;
+  size_t lz4_temp_bytes(size_t chunks) const { return codec == LZ4 ? lz4_compress_temp_bytes_used(ht_size, chunks) : 0; }
+  size_t placement_slots() const
+  {
+    const size_t n = codec == LZ4      ? lz4_placement_slots()
+                     : codec == Snappy ? snappy_placement_slots()
+                                       : cascaded_placement_slots(cascaded_elem);
+    if (n == 0)
+      throw std::runtime_error("compress: cannot find out how many workgroups the device holds");
+    return n;
+  }
   size_t placed_scratch_bytes(size_t chunks) const
   {
-    return 16 * chunks + 64 + lz4_placement_slots() * slot_bytes + 16 + lz4_temp_bytes(chunks);
+    return 16 * chunks + 64 + placement_slots() * slot_bytes + 16 + lz4_temp_bytes(chunks);
+  }
+  // what a caller's own scratch buffer must hold
+  size_t scratch_bytes() const
+  {
+    const size_t a = placed_scratch_bytes(kPlacedSlab), b = lists_bytes();
+    return a > b ? a : b;
   }
   // The manager's own scratch is as large as the calls so far needed (a buffer of a few chunks does not
-  // pay for two slabs of 2 GiB); the caller's is scratch_bytes() by contract.
+  // pay for the lists of a full pass); the caller's is scratch_bytes() by contract.
   size_t own_capacity = 0;
   uint8_t* ensure_scratch(size_t need)
   {
@@ -386,109 +296,53 @@ struct Core
   {
     if (reinterpret_cast<uintptr_t>(comp_buffer) & 7)
       throw std::runtime_error("compress: the container buffer must be 8-byte aligned");
-    const size_t n = cfg.num_chunks;
-    if (codec == LZ4) {
-      compress_placed(decomp_buffer, comp_buffer, cfg);
-      return;
-    }
-    // (one slab: nothing to overlap, one set of slots)
-    hipStream_t const placing = n > slab ? side_stream() : nullptr;
-    const size_t per_set = n < slab ? (n ? n : 1) : slab;
-    uint8_t* const s = ensure_scratch(scratch_bytes_for(per_set, placing ? 2 : 1));
-    const Layout lay = layout(n);
-    const uint8_t** in_ptrs = reinterpret_cast<const uint8_t**>(s);
-    size_t* in_bytes = reinterpret_cast<size_t*>(s + (size_t)slab * 8);
-    uint8_t** out_ptrs = reinterpret_cast<uint8_t**>(s + (size_t)slab * 16);
-    uint8_t* const slots0 = s + lists_bytes();
-    uint8_t* lz4_temp = reinterpret_cast<uint8_t*>(
-        (reinterpret_cast<uintptr_t>(slots0 + (placing ? 2 : 1) * per_set * slot_bytes) + 15) & ~uintptr_t(15));
-    header_kernel<<<1, 1, 0, stream>>>(comp_buffer, cfg.uncompressed_buffer_size, n, chunk_bytes, (uint32_t)lay.data,
-                                       format, format_header, format_header_bytes, cfg.get_status());
-    bool used[2] = {false, false};
-    size_t pass = 0;
-    for (size_t first = 0; first < n; first += slab, ++pass) {
-      const uint32_t count = (uint32_t)(n - first < slab ? n - first : slab);
-      const int b = placing ? (int)(pass & 1) : 0;
-      uint8_t* const slots = slots0 + (size_t)b * per_set * slot_bytes;
-      if (placing && used[b]) // (the gather of two slabs ago has emptied these slots)
-        check(hipStreamWaitEvent(stream, emptied[b], 0), "compress: wait for the slots");
-      slab_inputs_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, stream>>>(
-          decomp_buffer, cfg.uncompressed_buffer_size, chunk_bytes, first, count, slots, slot_bytes, in_ptrs, in_bytes,
-          out_ptrs);
-      // sizes go straight into the container's size array
-      size_t* sizes = reinterpret_cast<size_t*>(comp_buffer + lay.sizes) + first;
-      switch (codec) {
-      case LZ4:
-        check(lz4_launch_compress(in_ptrs, in_bytes, out_ptrs, sizes, ht_size, count, lz4_elem, lz4_temp, lz4_temp_bytes(per_set),
-                                  chunk_bytes, lz4_mode_from_environment(), stream),
-              "LZ4Manager::compress");
-        break;
-      case Snappy:
-        if (hipcompBatchedSnappyCompressAsync(reinterpret_cast<const void* const*>(in_ptrs), in_bytes, chunk_bytes, count,
-                                              nullptr, 0, reinterpret_cast<void* const*>(out_ptrs), sizes,
-                                              hipcompBatchedSnappyDefaultOpts, stream)
-            != hipcompSuccess)
-          throw std::runtime_error("SnappyManager::compress: batched compress failed");
-        break;
-      case Cascaded:
-        if (hipcompBatchedCascadedCompressAsync(reinterpret_cast<const void* const*>(in_ptrs), in_bytes, chunk_bytes,
-                                                count, nullptr, 0, reinterpret_cast<void* const*>(out_ptrs), sizes,
-                                                cascaded_opts, stream)
-            != hipcompSuccess)
-          throw std::runtime_error("CascadedManager::compress: batched compress failed");
-        break;
-      }
-      hipStream_t const where = placing ? placing : stream;
-      if (placing) {
-        check(hipEventRecord(filled[b], stream), "compress: slots filled");
-        check(hipStreamWaitEvent(placing, filled[b], 0), "compress: wait for the slab");
-      }
-      // (the running total of the container lives in its header: the placing of the slabs is in order
-      // because it is all on one stream)
-      slab_place_kernel<<<1, kBlock, 0, where>>>(comp_buffer, lay.sizes, lay.offsets, first, count, place_align);
-      slab_gather_kernel<<<(count + 3) / 4, kBlock, 0, where>>>(comp_buffer, lay.sizes, lay.offsets, lay.data, first,
-                                                                count, slots, slot_bytes);
-      if (placing) {
-        check(hipEventRecord(emptied[b], placing), "compress: slots emptied");
-        used[b] = true;
-      }
-    }
-    // the caller's stream goes on when the container is whole
-    for (int b = 0; b < 2; ++b)
-      if (placing && used[b])
-        check(hipStreamWaitEvent(stream, emptied[b], 0), "compress: wait for the container");
-    check(hipGetLastError(), "compress kernels");
-  }
-
-  // LZ4Manager::compress: see placed_scratch_bytes
-  void compress_placed(const uint8_t* decomp_buffer, uint8_t* comp_buffer, const hipcomp::CompressionConfig& cfg)
-  {
+    const int R = cascaded_opts.num_RLEs, D = cascaded_opts.num_deltas;
+    // (what hipcompBatchedCascadedCompressAsync refuses: cascaded_batch.cpp)
+    if (codec == Cascaded
+        && (R < 0 || D < 0 || R > 255 || D > 255
+            || round_up_to(4 + 4 * (size_t)(R + 1), cascaded_elem) + round_up_to((size_t)cascaded_elem * D, 4) > 64))
+      throw std::runtime_error("CascadedManager::compress: num_RLEs / num_deltas do not fit the 64-byte chunk metadata");
     const size_t n = cfg.num_chunks;
     const size_t per_pass = n < kPlacedSlab ? (n ? n : 1) : kPlacedSlab;
     uint8_t* const s = ensure_scratch(placed_scratch_bytes(per_pass));
     const Layout lay = layout(n);
     const uint8_t** in_ptrs = reinterpret_cast<const uint8_t**>(s);
     size_t* in_bytes = reinterpret_cast<size_t*>(s + per_pass * 8);
+    uint32_t* const ticket = reinterpret_cast<uint32_t*>(s + per_pass * 16);
     uint8_t* const slots = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(s + per_pass * 16 + 64) + 15) & ~uintptr_t(15));
     uint8_t* lz4_temp = reinterpret_cast<uint8_t*>(
-        (reinterpret_cast<uintptr_t>(slots + lz4_placement_slots() * slot_bytes) + 15) & ~uintptr_t(15));
+        (reinterpret_cast<uintptr_t>(slots + placement_slots() * slot_bytes) + 15) & ~uintptr_t(15));
     header_kernel<<<1, 1, 0, stream>>>(comp_buffer, cfg.uncompressed_buffer_size, n, chunk_bytes, (uint32_t)lay.data,
                                        format, format_header, format_header_bytes, cfg.get_status());
     for (size_t first = 0; first < n; first += per_pass) {
       const uint32_t count = (uint32_t)(n - first < per_pass ? n - first : per_pass);
       slab_inputs_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, stream>>>(
-          decomp_buffer, cfg.uncompressed_buffer_size, chunk_bytes, first, count, nullptr, 0, in_ptrs, in_bytes, nullptr);
-      Lz4Placement place;
+          decomp_buffer, cfg.uncompressed_buffer_size, chunk_bytes, first, count, in_ptrs, in_bytes);
+      Placement place;
       place.slots = slots;
       place.slot_bytes = slot_bytes;
       place.data = comp_buffer + lay.data;
       place.cursor = reinterpret_cast<unsigned long long*>(comp_buffer + offsetof(CommonHeader, comp_data_size));
       place.offsets = reinterpret_cast<unsigned long long*>(comp_buffer + lay.offsets) + first;
       place.align = place_align;
+      // sizes go straight into the container's size array
       size_t* sizes = reinterpret_cast<size_t*>(comp_buffer + lay.sizes) + first;
-      check(lz4_launch_compress(in_ptrs, in_bytes, nullptr, sizes, ht_size, count, lz4_elem, lz4_temp, lz4_temp_bytes(per_pass),
-                                chunk_bytes, lz4_mode_from_environment(), stream, &place),
-            "LZ4Manager::compress");
+      switch (codec) {
+      case LZ4:
+        check(lz4_launch_compress(in_ptrs, in_bytes, nullptr, sizes, ht_size, count, lz4_elem, lz4_temp,
+                                  lz4_temp_bytes(per_pass), chunk_bytes, lz4_mode_from_environment(), stream, &place),
+              "LZ4Manager::compress");
+        break;
+      case Snappy:
+        check(snappy_launch_compress_placed(in_ptrs, in_bytes, sizes, count, ticket, place, stream),
+              "SnappyManager::compress");
+        break;
+      case Cascaded:
+        check(cascaded_launch_compress_placed(in_ptrs, in_bytes, sizes, count, (int)cascaded_opts.type, cascaded_elem, R, D,
+                                              cascaded_opts.use_bp ? 1 : 0, ticket, place, stream),
+              "CascadedManager::compress");
+        break;
+      }
     }
     check(hipGetLastError(), "compress kernels");
   }
@@ -718,6 +572,7 @@ CascadedManager::CascadedManager(const hipcompBatchedCascadedOpts_t& options, hi
   std::memcpy(m.format_header.bytes, &options, sizeof(options));
   m.cascaded_opts = options;
   m.cascaded_opts.chunk_size = 4096;
+  m.cascaded_elem = (int)elem;
   m.place_align = 8;
   m.finish_init(slot);
 }

@@ -55,6 +55,7 @@
 // Decoder: reference src/LZ4Kernels.hiph:971-1097 decompressStream.
 
 #include "lz4_launch.hpp"
+#include "placement.hiph"
 #include "wave_utils.hpp"
 
 

@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #include "hipcomp/shared_types.h"
+#include "placement.hpp"
 
 namespace hcamd {
 
@@ -49,21 +50,8 @@ Lz4Mode lz4_mode_from_environment();
 // device-table waves (max(ht_size, 8) uint16 each, 16-byte aligned).  Too small for the lists:
 // no routing, the LDS shape for all; too small for the header: one chunk per wave.  nullptr / 0
 // is accepted (the same).  batch must be > 0 and < 2^31.
-// Placement (the high-level managers, csrc/hlif.hip; the batched API leaves it empty): a chunk is not
-// written where out_ptrs says but into a slot of the wave's own, and when it is done -- its size known --
-// the wave takes its place in the container with one atomic add on the container's byte count
-// (completion order: the reference's scheme, hipcomp_common_deps/hlif_shared.hiph:165-232), copies it
-// there and notes where.  One slot per resident wave (lz4_placement_slots()) instead of one per chunk,
-// and no pass over the compressed bytes afterwards.  out_ptrs is not read then (may be null).
-struct Lz4Placement
-{
-  uint8_t* slots = nullptr;              // nullptr: off
-  unsigned long long slot_bytes = 0;     // at least the maximal compressed chunk
-  uint8_t* data = nullptr;               // where the container's chunks begin
-  unsigned long long* cursor = nullptr;  // the container's byte count so far (8-byte aligned)
-  unsigned long long* offsets = nullptr; // per chunk of the batch: where it went, relative to `data`
-  uint32_t align = 1;                    // chunk starts are multiples of it
-};
+// Placement: see placement.hpp.
+typedef Placement Lz4Placement;
 // how many slots a launch can ask for (the most waves any of the compress kernels holds on the device)
 size_t lz4_placement_slots();
 

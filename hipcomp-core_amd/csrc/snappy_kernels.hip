@@ -30,6 +30,8 @@
 // behaviour of the reference is replaced by an error status.
 
 #include "snappy_launch.hpp"
+#include "lz4_launch.hpp" // num_cus_of_current_device
+#include "placement.hiph"
 #include "wave_utils.hpp"
 
 namespace hcamd {
@@ -79,37 +81,11 @@ constexpr int kSpan = HC_SNAPPY_SPAN;
 static_assert(kSpan >= 8 && kSpan < 64, "the straight path's pick() relies on bit 63 of `events` never being set");
 constexpr uint32_t kStraightReach = 64; // (two registers of words: all 64 lanes of the next window are there)
 
-__global__ __launch_bounds__(kWave) void snappy_compress_kernel(
-    const uint8_t* const* __restrict__ in_ptrs,
-    const size_t* __restrict__ in_bytes,
-    uint8_t* const* __restrict__ out_ptrs,
-    size_t* __restrict__ out_bytes,
-    const size_t* __restrict__ out_available, uint32_t* __restrict__ statuses)
+// One chunk by the calling wave: src[0 .. len) -> dst, -> the compressed bytes.  hash_map: kHashEntries
+// uint16 in LDS.
+__device__ __forceinline__ uint32_t snappy_encode_chunk(
+    cgptr __restrict__ src, const uint32_t len, gptr __restrict__ dst, uint16_t* hash_map, const int lane)
 {
-  __shared__ __attribute__((aligned(16))) uint16_t hash_map[kHashEntries];
-
-  const int lane = (int)threadIdx.x;
-  const size_t chunk = blockIdx.x;
-  cgptr __restrict__ src = to_global(uniform_ptr(in_ptrs[chunk]));
-  const uint32_t len = uniform((uint32_t)in_bytes[chunk]);
-  gptr __restrict__ dst = to_global(uniform_ptr(out_ptrs[chunk]));
-  // (only through hipcomp::gpu_snap, the reference's internal entry point -- the batched API has neither:
-  // reference compression.hiph:307-311 and :383 let the encoder run and report an output that did not
-  // fit; here a buffer smaller than the worst case for this input is not written to at all)
-  if (out_available != nullptr) {
-    const size_t room = uniform((uint64_t)out_available[chunk]);
-    if (room != 0 && room < (size_t)32 + len + len / 6) { // reference get_max_compressed_length
-      if (lane == 0) {
-        out_bytes[chunk] = 0;
-        if (statuses)
-          statuses[chunk] = 1;
-      }
-      return;
-    }
-  }
-  if (statuses != nullptr && lane == 0)
-    statuses[chunk] = 0;
-
   // varint of the uncompressed length (reference :316-322)
   uint32_t c = 0;
   {
@@ -540,8 +516,66 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     next_hi = load_u32_any(src + min(pos + 64u + (uint32_t)lane, last_word));
     wnd = next;
   }
+  return c;
+}
+
+__global__ __launch_bounds__(kWave) void snappy_compress_kernel(
+    const uint8_t* const* __restrict__ in_ptrs,
+    const size_t* __restrict__ in_bytes,
+    uint8_t* const* __restrict__ out_ptrs,
+    size_t* __restrict__ out_bytes,
+    const size_t* __restrict__ out_available, uint32_t* __restrict__ statuses)
+{
+  __shared__ __attribute__((aligned(16))) uint16_t hash_map[kHashEntries];
+
+  const int lane = (int)threadIdx.x;
+  const size_t chunk = blockIdx.x;
+  cgptr __restrict__ src = to_global(uniform_ptr(in_ptrs[chunk]));
+  const uint32_t len = uniform((uint32_t)in_bytes[chunk]);
+  gptr __restrict__ dst = to_global(uniform_ptr(out_ptrs[chunk]));
+  // (only through hipcomp::gpu_snap, the reference's internal entry point -- the batched API has neither:
+  // reference compression.hiph:307-311 and :383 let the encoder run and report an output that did not
+  // fit; here a buffer smaller than the worst case for this input is not written to at all)
+  if (out_available != nullptr) {
+    const size_t room = uniform((uint64_t)out_available[chunk]);
+    if (room != 0 && room < (size_t)32 + len + len / 6) { // reference get_max_compressed_length
+      if (lane == 0) {
+        out_bytes[chunk] = 0;
+        if (statuses)
+          statuses[chunk] = 1;
+      }
+      return;
+    }
+  }
+  if (statuses != nullptr && lane == 0)
+    statuses[chunk] = 0;
+  const uint32_t c = snappy_encode_chunk(src, len, dst, hash_map, lane);
   if (lane == 0)
     out_bytes[chunk] = c;
+}
+
+// The same for the high-level manager (placement.hpp): a grid as large as the device holds workgroups, each
+// takes chunks off a ticket counter, compresses into its slot and moves the chunk to its place in the
+// container.  The copy reads what this wave has just written (its own stores, in order: the lines are in
+// the L2), so the compressed bytes cross the HBM once.
+__global__ __launch_bounds__(kWave) void snappy_compress_placed_kernel(
+    const uint8_t* const* __restrict__ in_ptrs,
+    const size_t* __restrict__ in_bytes,
+    size_t* __restrict__ out_bytes, const uint32_t batch, uint32_t* __restrict__ ticket, const Placement place)
+{
+  __shared__ __attribute__((aligned(16))) uint16_t hash_map[kHashEntries];
+  const int lane = (int)threadIdx.x;
+  gptr __restrict__ slot = to_global(place.slots + (size_t)blockIdx.x * place.slot_bytes);
+  for (uint32_t chunk = next_chunk(ticket, lane); chunk < batch; chunk = next_chunk(ticket, lane)) {
+    cgptr __restrict__ src = to_global(uniform_ptr(in_ptrs[chunk]));
+    const uint32_t len = uniform((uint32_t)in_bytes[chunk]);
+    const uint32_t c = snappy_encode_chunk(src, len, slot, hash_map, lane);
+    if (lane == 0)
+      out_bytes[chunk] = c;
+    place_chunk(place, chunk, slot, c, lane);
+    // (every load of the copy has come back when it returns -- its stores needed them -- so the next chunk may
+    // write the slot)
+  }
 }
 
 // Varint preamble (reference get_uncompressed_sizes_kernel,
@@ -956,6 +990,43 @@ void snappy_launch_compress(
 {
   snappy_compress_kernel<<<dim3((unsigned)batch), dim3(kWave), 0, stream>>>(
       in_ptrs, in_bytes, out_ptrs, out_bytes, out_available, statuses);
+}
+
+namespace {
+unsigned placed_grid(size_t batch)
+{
+  static unsigned resident = 0; // (one device per process in this library's use; the same on every MI355X)
+  if (resident == 0) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, snappy_compress_placed_kernel, kWave, 0) != hipSuccess
+        || per_cu <= 0) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    resident = (unsigned)per_cu * (unsigned)num_cus_of_current_device();
+  }
+  return batch < resident ? (unsigned)batch : resident;
+}
+} // namespace
+
+size_t snappy_placement_slots()
+{
+  return placed_grid(~size_t(0));
+}
+
+hipError_t snappy_launch_compress_placed(
+    const uint8_t* const* in_ptrs, const size_t* in_bytes, size_t* out_bytes, size_t batch,
+    uint32_t* ticket, const Placement& place, hipStream_t stream)
+{
+  const unsigned grid = placed_grid(batch);
+  if (grid == 0 || batch >= 0xFFFFFFFFull)
+    return hipErrorInvalidValue;
+  const hipError_t e = hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess)
+    return e;
+  snappy_compress_placed_kernel<<<dim3(grid), dim3(kWave), 0, stream>>>(in_ptrs, in_bytes, out_bytes, (uint32_t)batch,
+                                                                       ticket, place);
+  return hipGetLastError();
 }
 
 void snappy_launch_decompress(

@@ -50,6 +50,9 @@ namespace {
 // throughput, eight more decompress launches -- measured useless and removed in round 4.)
 constexpr uint32_t kPartMeta = 8;
 constexpr uint32_t CB = 4096;
+#ifndef HC_CASC_STOP_AFTER
+#define HC_CASC_STOP_AFTER 0 // (measurement builds only: see the encoder's fast path)
+#endif
 #ifndef HC_CASC_WAVES
 #define HC_CASC_WAVES 1 // 6 KiB of LDS per wave: separate blocks pack 25 per CU
 #endif
@@ -873,6 +876,20 @@ __device__ __forceinline__ uint32_t cascaded_encode_partition(
       uint32_t img = 0; // the chunk metadata image: lane j holds its word j (reference :1004-1014)
       uint32_t v[16];
       load16_global(in + (size_t)c * CB, n, v, lane);
+      // (measurement builds, scripts/pmc_cascaded_stages.sh: a sub-chunk is left behind stage HC_CASC_STOP_AFTER --
+      // 1 RLE, 2 its lengths packed, 3 delta, 4 the second RLE, 5 its lengths packed -- and the counters of two such
+      // builds differ by what the stage between them executes; the output is then not a stream)
+#if HC_CASC_STOP_AFTER
+      int stage = 0;
+#define HC_STAGE_DONE()                       \
+  if (++stage == HC_CASC_STOP_AFTER) {        \
+    cut_short = true;                         \
+    break;                                    \
+  }
+      bool cut_short = false;
+#else
+#define HC_STAGE_DONE()
+#endif
       // (Touching the next sub-chunk's lines here, so that its loads hit the L2 -- a wave meets the HBM's
       // latency 16 times per partition -- made the kernel slower, 1958 -> 1825 GB/s: it is not what the
       // waves wait for.)
@@ -886,6 +903,7 @@ __device__ __forceinline__ uint32_t cascaded_encode_partition(
 #pragma unroll
           for (int k = 0; k < 16; ++k)
             v[k] = 0; // (the registers are free from here on: what comes next loads its own)
+          HC_STAGE_DONE()
           const uint32_t ob = write_array4<true>(out, cur, limit, X, Eb, m, bp, lane);
           if (ob == 0xFFFFFFFFu) {
             use = false;
@@ -896,6 +914,7 @@ __device__ __forceinline__ uint32_t cascaded_encode_partition(
           n = m;
           --rr;
           in_regs = false;
+          HC_STAGE_DONE()
         }
         if (dr > 0) { // reference :955-977
           if (n == 0) { // undefined in the reference (:323); raw fallback here
@@ -910,10 +929,22 @@ __device__ __forceinline__ uint32_t cascaded_encode_partition(
           n -= 1;
           --dr;
           in_regs = true;
+          HC_STAGE_DONE()
         }
       }
+#undef HC_STAGE_DONE
       if (!use)
         break;
+#if HC_CASC_STOP_AFTER
+      if (cut_short) {
+        if (in_regs) { // (what the stage left in registers counts as used)
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            asm volatile("" ::"v"(v[k]));
+        }
+        continue;
+      }
+#endif
       if (in_regs)
         store16_lds(X, n, v, lane);
 #pragma unroll

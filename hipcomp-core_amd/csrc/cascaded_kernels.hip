@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, HC_CASC_OCC) void cascaded_
 // The same for the high-level manager (placement.hpp; as snappy_compress_placed_kernel): one wave per
 // workgroup, as many workgroups as the device holds, partitions off a ticket counter, each compressed into the
 // wave's slot and moved to its place in the container.
+// (5 waves per SIMD instead of 6, no spills: 1 990 -> 1 915 GB/s)
 template <int S>
 __global__ __launch_bounds__(kWave, HC_CASC_OCC) void cascaded_compress_placed_kernel(
     const uint8_t* const* __restrict__ in_ptrs, const size_t* __restrict__ in_bytes_arr,
@@ -1106,7 +1107,9 @@ __global__ __launch_bounds__(kWave, HC_CASC_OCC) void cascaded_compress_placed_k
     const uint32_t total = cascaded_encode_partition<S>(in, in_bytes64, slot, smem, type_tag, R, D, bp, lane);
     if (lane == 0)
       out_bytes_arr[part] = total;
-    place_chunk(place, part, slot, total, lane); // (an empty partition takes no room: offset = the cursor as it stands)
+    // (an empty partition takes no room: offset = the cursor as it stands.  Measured at 100 000 partitions: the
+    // manager's compress 3.14 ms, without this copy 3.05, without its atomic add either 3.01; the batched call 2.78)
+    place_chunk(place, part, slot, total, lane);
   }
 }
 

@@ -516,6 +516,38 @@ __device__ __forceinline__ void load16_global(cgptr src, uint32_t n, uint32_t (&
       v[k] = base[min(64u * k + at, n - 1u)];
   }
 }
+// The same for a full sub-chunk (1024 elements, all but a partition's last one): ONE statement, the base in
+// scalar registers, the lane's byte offset one 32-bit register, the steps the loads' immediate offsets.  (As
+// written above the compiler made a 64-bit address per load -- three vector instructions each, 48 of the
+// encoder's 926 per sub-chunk -- and a compare and two branches around every one of them.)  The wait is part
+// of the statement: the compiler does not know that the registers are in flight.
+__device__ __forceinline__ void load16_global_full(cgptr src, uint32_t (&v)[16], int lane)
+{
+  const uint32_t at = (uint32_t)lane << 2;
+  asm volatile("s_nop 4\n\t" // (a scalar register written just before is not read as an address too early)
+               "global_load_dword %0, %16, %17\n\t"
+               "global_load_dword %1, %16, %17 offset:256\n\t"
+               "global_load_dword %2, %16, %17 offset:512\n\t"
+               "global_load_dword %3, %16, %17 offset:768\n\t"
+               "global_load_dword %4, %16, %17 offset:1024\n\t"
+               "global_load_dword %5, %16, %17 offset:1280\n\t"
+               "global_load_dword %6, %16, %17 offset:1536\n\t"
+               "global_load_dword %7, %16, %17 offset:1792\n\t"
+               "global_load_dword %8, %16, %17 offset:2048\n\t"
+               "global_load_dword %9, %16, %17 offset:2304\n\t"
+               "global_load_dword %10, %16, %17 offset:2560\n\t"
+               "global_load_dword %11, %16, %17 offset:2816\n\t"
+               "global_load_dword %12, %16, %17 offset:3072\n\t"
+               "global_load_dword %13, %16, %17 offset:3328\n\t"
+               "global_load_dword %14, %16, %17 offset:3584\n\t"
+               "global_load_dword %15, %16, %17 offset:3840\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                 "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]),
+                 "=&v"(v[15])
+               : "v"(at), "s"(src)
+               : "memory");
+}
 __device__ __forceinline__ void load16_lds(const uint8_t* X, uint32_t n, uint32_t (&v)[16], int lane)
 {
 #pragma unroll
@@ -875,7 +907,10 @@ __device__ __forceinline__ uint32_t cascaded_encode_partition(
       uint32_t n = min(N - c * CE, CE);
       uint32_t img = 0; // the chunk metadata image: lane j holds its word j (reference :1004-1014)
       uint32_t v[16];
-      load16_global(in + (size_t)c * CB, n, v, lane);
+      if (n == CE)
+        load16_global_full(in + (size_t)c * CB, v, lane);
+      else
+        load16_global(in + (size_t)c * CB, n, v, lane);
       // (measurement builds, scripts/pmc_cascaded_stages.sh: a sub-chunk is left behind stage HC_CASC_STOP_AFTER --
       // 1 RLE, 2 its lengths packed, 3 delta, 4 the second RLE, 5 its lengths packed -- and the counters of two such
       // builds differ by what the stage between them executes; the output is then not a stream)

@@ -473,12 +473,15 @@ __device__ __forceinline__ uint32_t next_element(uint32_t cur, uint32_t next)
   return (uint32_t)__builtin_amdgcn_update_dpp(rolled, (int)cur, 0x130, 0xF, 0xF, false);       // wave_shl:1
 }
 
-// 64-lane reductions on the DPP crossbar: the result is lane 63's
+// 64-lane reductions on the DPP crossbar: the result is lane 63's.  (A lane without a source takes the
+// operation's identity: written that way the compiler folds the move into the minimum / maximum itself --
+// one instruction per step; with the lane's own value as the fallback it was three: a copy, the move, the
+// operation -- 72 of the encoder's vector instructions per sub-chunk.)
 __device__ __forceinline__ int32_t wave_min_i32(int32_t v)
 {
 #define HC_STEP(CTRL, MASK)                                                                          \
   {                                                                                                  \
-    const int32_t u = __builtin_amdgcn_update_dpp(v, v, CTRL, MASK, 0xF, false);                     \
+    const int32_t u = __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, MASK, 0xF, false);            \
     v = u < v ? u : v;                                                                               \
   }
   HC_STEP(0x111, 0xF) HC_STEP(0x112, 0xF) HC_STEP(0x114, 0xF) HC_STEP(0x118, 0xF) HC_STEP(0x142, 0xA) HC_STEP(0x143, 0xC)
@@ -489,7 +492,7 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
 {
 #define HC_STEP(CTRL, MASK)                                                                          \
   {                                                                                                  \
-    const int32_t u = __builtin_amdgcn_update_dpp(v, v, CTRL, MASK, 0xF, false);                     \
+    const int32_t u = __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, MASK, 0xF, false);       \
     v = u > v ? u : v;                                                                               \
   }
   HC_STEP(0x111, 0xF) HC_STEP(0x112, 0xF) HC_STEP(0x114, 0xF) HC_STEP(0x118, 0xF) HC_STEP(0x142, 0xA) HC_STEP(0x143, 0xC)
@@ -601,8 +604,12 @@ __device__ __forceinline__ void store16_lds(uint8_t* X, uint32_t n, const uint32
 // X[0 .. m), the positions behind their last elements to Eb[0 .. m) (padded layouts), both filled
 // up to a multiple of 32 entries for the packer (values: copies of the last one; ends: going on at
 // the last run's length).  Returns m.
+// FULL: n == 1024 (a full sub-chunk, all but a partition's last one: the steps' tests on n are gone).
+template <bool FULL = false>
 __device__ __forceinline__ uint32_t rle16(const uint32_t (&v)[16], uint32_t n, uint8_t* X, uint8_t* Eb, int lane)
 {
+  if (FULL)
+    n = 1024u;
   uint32_t m = 0, last = 0;
   const uint32_t xbase = uniform((uint32_t)(uintptr_t)(const HC_LDS uint8_t*)X);
   // the run ends of a step: value and end position to consecutive ranks
@@ -934,7 +941,7 @@ __device__ __forceinline__ uint32_t cascaded_encode_partition(
         if (rr > 0) { // reference :913-953
           if (!in_regs)
             load16_lds(X, n, v, lane);
-          const uint32_t m = rle16(v, n, X, Eb, lane);
+          const uint32_t m = (in_regs && n == CE) ? rle16<true>(v, n, X, Eb, lane) : rle16(v, n, X, Eb, lane);
 #pragma unroll
           for (int k = 0; k < 16; ++k)
             v[k] = 0; // (the registers are free from here on: what comes next loads its own)

@@ -555,9 +555,9 @@ __device__ __forceinline__ void load16_lds(const uint8_t* X, uint32_t n, uint32_
 {
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    v[k] = 0;
-    if (64u * k < n)
-      v[k] = *reinterpret_cast<const uint32_t*>(X + x4_addr(64u * k + (uint32_t)lane)); // (behind n: whatever lies there, in bounds)
+    // (all sixteen whatever n: behind n whatever lies there, in bounds, used by nothing -- four loads too many
+    // on a sorted column's arrays, sixteen tests and branches fewer)
+    v[k] = *reinterpret_cast<const uint32_t*>(X + x4_addr(64u * k + (uint32_t)lane));
   }
   // (all of them waited for here, once: what follows stores to LDS under conditions between its uses of
   // v[k], and the compiler, unable to count those stores, would wait for an empty LDS queue in front of
@@ -569,16 +569,13 @@ __device__ __forceinline__ void load16_lds(const uint8_t* X, uint32_t n, uint32_
 
 // v[k] <- element i + 1 minus element i (i = 64 k + lane): the delta layer on n >= 1 elements in
 // registers (reference block_delta_compress :317-328); what lands at and behind n - 1 is not used.
-// (Sixteen independent tests, not a loop that is left at the first step behind n: that form -- which pays in
-// rle16 -- ran this kernel 14 % slower here, 4 % slower in load16_lds, and in store16_lds 1 % faster alone but
-// 3 % slower beside rle16's.)
+// (All sixteen steps whatever n, like load16_lds: no test at all.  A loop that is left at the first step behind
+// n -- the form that pays in rle16 -- ran this kernel 14 % slower here and 4 % slower in load16_lds.)
 __device__ __forceinline__ void delta16(uint32_t (&v)[16], uint32_t n)
 {
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    if (64u * k < n) {
-      v[k] = (k + 1 < 16 ? next_element(v[k], v[(k + 1) % 16]) : from_lane_above(v[k], 0u)) - v[k];
-    }
+    v[k] = (k + 1 < 16 ? next_element(v[k], v[(k + 1) % 16]) : from_lane_above(v[k], 0u)) - v[k];
   }
 }
 

@@ -1998,6 +1998,16 @@ __device__ __forceinline__ void cascaded_decode_partition4(
       for (int k = 0; k < (int)kStagePerLane; ++k)
         asm volatile("" : "+v"(pf[k]));
 #endif
+      if (n == (int)CE) { // a full sub-chunk (all but a partition's last one): no tests, one address, immediate steps
+        const uint8_t* px0 = X + x4_addr(4u * (uint32_t)lane);
+        HC_GLOBAL uint32_t* d0 = dst + 4u * (uint32_t)lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { // (x4_addr(e + 256 q) = x4_addr(e) + 4 (256 + 8) q for e < 256)
+          const uint32_t* px = reinterpret_cast<const uint32_t*>(px0 + 1056 * q);
+          u32x4 t = {px[0], px[1], px[2], px[3]};
+          *reinterpret_cast<HC_GLOBAL u32x4_unaligned*>(d0 + 256 * q) = t;
+        }
+      } else
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint32_t e = 4u * ((uint32_t)lane + 64u * q);

@@ -1148,7 +1148,8 @@ __global__ __launch_bounds__(kWave, HC_CASC_OCC) void cascaded_compress_placed_k
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // wave_lds_bytes<S>()
   const int lane = lane_id();
   gptr slot = to_global(place.slots + (size_t)blockIdx.x * place.slot_bytes);
-  for (uint32_t part = next_chunk(ticket, lane); part < batch; part = next_chunk(ticket, lane)) {
+  for (uint32_t part = next_chunk(ticket, lane); part < batch;) {
+    const uint32_t asked = ask_next_chunk(ticket, lane);
     cgptr in = to_global(uniform_ptr(in_ptrs[part]));
     const size_t in_bytes64 = uniform((uint64_t)in_bytes_arr[part]);
     const uint32_t total = cascaded_encode_partition<S>(in, in_bytes64, slot, smem, type_tag, R, D, bp, lane);
@@ -1157,6 +1158,7 @@ __global__ __launch_bounds__(kWave, HC_CASC_OCC) void cascaded_compress_placed_k
     // (an empty partition takes no room: offset = the cursor as it stands.  Measured at 100 000 partitions: the
     // manager's compress 3.14 ms, without this copy 3.05, without its atomic add either 3.01; the batched call 2.78)
     place_chunk(place, part, slot, total, lane);
+    part = chunk_asked_for(asked);
   }
 }
 
@@ -2471,9 +2473,6 @@ hipError_t cascaded_launch_compress_placed(
   const unsigned resident = placed_resident(elem_size);
   if (resident == 0 || batch == 0 || batch >= 0xFFFFFFFFull)
     return hipErrorInvalidValue;
-  const hipError_t e = hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
-  if (e != hipSuccess)
-    return e;
   const PlacedShape sh = placed_shape(elem_size);
   sh.k<<<dim3(batch < resident ? (unsigned)batch : resident), dim3(kWave), sh.lds, stream>>>(
       in_ptrs, in_bytes, out_bytes, (uint32_t)batch, type_tag, num_rles, num_deltas, use_bp, ticket, place);

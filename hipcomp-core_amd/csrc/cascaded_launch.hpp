@@ -15,7 +15,7 @@ void cascaded_launch_compress(
     uint8_t* const* out_ptrs, size_t* out_bytes, size_t batch, int type_tag,
     int elem_size, int num_rles, int num_deltas, int use_bp, hipStream_t stream);
 
-// The high-level manager's compress (placement.hpp): `ticket` = one word of device memory of the call's own,
+// The high-level manager's compress (placement.hpp): `ticket` = one word of device memory of the call's own, ZERO when the kernel starts (the caller zeroes it on the stream),
 // place.slots = cascaded_placement_slots(elem_size) slots.  out_ptrs does not exist here.
 size_t cascaded_placement_slots(int elem_size);
 hipError_t cascaded_launch_compress_placed(

@@ -116,12 +116,16 @@ __global__ void header_kernel(
     *status = hipcompSuccess;
 }
 
-// chunk list of one pass: inputs are slices of the buffer
+// chunk list of one pass: inputs are slices of the buffer; the pass's chunk ticket counter = 0 (the Snappy /
+// Cascaded kernels draw their chunks from it; zeroed here, by a kernel on the stream, not by hipMemsetAsync:
+// lz4_kernels.hip, lz4_launch_decompress, says what was seen with a memset node in a captured graph)
 __global__ void slab_inputs_kernel(
     const uint8_t* decomp, uint64_t decomp_bytes, uint64_t chunk_bytes, uint64_t first, uint32_t count,
-    const uint8_t** in_ptrs, size_t* in_bytes)
+    const uint8_t** in_ptrs, size_t* in_bytes, uint32_t* ticket)
 {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0)
+    *ticket = 0;
   if (i >= count)
     return;
   const uint64_t at = (first + i) * chunk_bytes;
@@ -317,7 +321,7 @@ struct Core
     for (size_t first = 0; first < n; first += per_pass) {
       const uint32_t count = (uint32_t)(n - first < per_pass ? n - first : per_pass);
       slab_inputs_kernel<<<(count + kBlock - 1) / kBlock, kBlock, 0, stream>>>(
-          decomp_buffer, cfg.uncompressed_buffer_size, chunk_bytes, first, count, in_ptrs, in_bytes);
+          decomp_buffer, cfg.uncompressed_buffer_size, chunk_bytes, first, count, in_ptrs, in_bytes, ticket);
       Placement place;
       place.slots = slots;
       place.slot_bytes = slot_bytes;

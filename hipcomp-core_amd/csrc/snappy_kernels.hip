@@ -566,7 +566,8 @@ __global__ __launch_bounds__(kWave) void snappy_compress_placed_kernel(
   __shared__ __attribute__((aligned(16))) uint16_t hash_map[kHashEntries];
   const int lane = (int)threadIdx.x;
   gptr __restrict__ slot = to_global(place.slots + (size_t)blockIdx.x * place.slot_bytes);
-  for (uint32_t chunk = next_chunk(ticket, lane); chunk < batch; chunk = next_chunk(ticket, lane)) {
+  for (uint32_t chunk = next_chunk(ticket, lane); chunk < batch;) {
+    const uint32_t asked = ask_next_chunk(ticket, lane);
     cgptr __restrict__ src = to_global(uniform_ptr(in_ptrs[chunk]));
     const uint32_t len = uniform((uint32_t)in_bytes[chunk]);
     const uint32_t c = snappy_encode_chunk(src, len, slot, hash_map, lane);
@@ -575,6 +576,7 @@ __global__ __launch_bounds__(kWave) void snappy_compress_placed_kernel(
     place_chunk(place, chunk, slot, c, lane);
     // (every load of the copy has come back when it returns -- its stores needed them -- so the next chunk may
     // write the slot)
+    chunk = chunk_asked_for(asked);
   }
 }
 
@@ -1021,9 +1023,6 @@ hipError_t snappy_launch_compress_placed(
   const unsigned grid = placed_grid(batch);
   if (grid == 0 || batch >= 0xFFFFFFFFull)
     return hipErrorInvalidValue;
-  const hipError_t e = hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
-  if (e != hipSuccess)
-    return e;
   snappy_compress_placed_kernel<<<dim3(grid), dim3(kWave), 0, stream>>>(in_ptrs, in_bytes, out_bytes, (uint32_t)batch,
                                                                        ticket, place);
   return hipGetLastError();

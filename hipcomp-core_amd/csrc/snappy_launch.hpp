@@ -15,7 +15,7 @@ void snappy_launch_compress(
     uint8_t* const* out_ptrs, size_t* out_bytes, size_t batch,
     hipStream_t stream, const size_t* out_available = nullptr, uint32_t* statuses = nullptr);
 
-// The high-level manager's compress (placement.hpp): `ticket` = one word of device memory of the call's own,
+// The high-level manager's compress (placement.hpp): `ticket` = one word of device memory of the call's own, ZERO when the kernel starts (the caller zeroes it on the stream),
 // place.slots = snappy_placement_slots() slots.  out_ptrs does not exist here.
 size_t snappy_placement_slots();
 hipError_t snappy_launch_compress_placed(

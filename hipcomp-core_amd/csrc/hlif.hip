@@ -30,9 +30,11 @@
 #include "hipcomp/snappy.hpp"
 
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace hcamd {
 namespace hlif {
@@ -184,12 +186,44 @@ inline void check(hipError_t e, const char* what)
     throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// The status word of a configuration (pinned host memory: kernels write it, the host reads it).  A
+// configuration is made per call in the reference's API; hipHostMalloc + hipHostFree per call were a fifth of a
+// 3 ms compress.  Words come from pages of 64 that are handed out again and never given back (a process that
+// configures holds a few hundred bytes of pinned memory until it ends; the list is leaked on purpose: a
+// configuration in a static of the caller's may outlive this library's own statics).
+struct StatusPool
+{
+  std::mutex lock;
+  std::vector<hipcompStatus_t*> spare;
+  hipcompStatus_t* take()
+  {
+    std::lock_guard<std::mutex> g(lock);
+    if (spare.empty()) {
+      hipcompStatus_t* page = nullptr;
+      check(hipHostMalloc((void**)&page, 64 * sizeof(hipcompStatus_t), hipHostMallocDefault), "hipHostMalloc(status)");
+      for (int i = 0; i < 64; ++i)
+        spare.push_back(page + i);
+    }
+    hipcompStatus_t* p = spare.back();
+    spare.pop_back();
+    return p;
+  }
+  void give(hipcompStatus_t* p)
+  {
+    std::lock_guard<std::mutex> g(lock);
+    spare.push_back(p);
+  }
+};
+inline StatusPool& status_pool()
+{
+  static StatusPool* pool = new StatusPool;
+  return *pool;
+}
 inline std::shared_ptr<hipcompStatus_t> new_status()
 {
-  hipcompStatus_t* p = nullptr;
-  check(hipHostMalloc((void**)&p, sizeof(hipcompStatus_t), hipHostMallocDefault), "hipHostMalloc(status)");
+  hipcompStatus_t* p = status_pool().take();
   *p = hipcompSuccess;
-  return std::shared_ptr<hipcompStatus_t>(p, [](hipcompStatus_t* q) { (void)hipHostFree(q); });
+  return std::shared_ptr<hipcompStatus_t>(p, [](hipcompStatus_t* q) { status_pool().give(q); });
 }
 
 // What the three managers share: the container, the slabs, the scratch space.  The codec is
@@ -727,7 +761,10 @@ hipcompStatus_t hipcompHlifCompress(
   HCAMD_REQUIRE_NOT_NULL(fn, manager);
   HCAMD_REQUIRE_NOT_NULL(fn, device_container);
   return guarded(fn, [&] {
-    manager->last_comp.reset(new hipcomp::CompressionConfig(manager->lz4->configure_compression(uncompressed_bytes)));
+    // (a configuration owns a pinned status word: made anew only when the size changes -- hipHostMalloc /
+    // hipHostFree per call were a fifth of a 3 ms compress)
+    if (!manager->last_comp || manager->last_comp->uncompressed_buffer_size != uncompressed_bytes)
+      manager->last_comp.reset(new hipcomp::CompressionConfig(manager->lz4->configure_compression(uncompressed_bytes)));
     manager->last_was_compress = true;
     manager->lz4->compress(static_cast<const uint8_t*>(device_uncompressed), static_cast<uint8_t*>(device_container),
                            *manager->last_comp);

@@ -474,6 +474,22 @@ def kernel_source_id(read=None) -> str:
     return h.hexdigest()[:16]
 
 
+def device_asm_id():
+    """Identifies the DEVICE code of the build at hand: sha256 over the assembly the kernel objects were made from
+    (csrc/build/*.gfx950.s, kept by the Makefile).  A change to host code or comments in a kernel source file
+    changes kernel_source_id() but not this; None when the build directory is not there."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "hipcomp-core_amd", "csrc", "build", "*.gfx950.s")))
+    if not files:
+        return None
+    h = hashlib.sha256()
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 PROFILED_ROWS = None
 
 
@@ -484,7 +500,7 @@ def profiled(label: str, phase: str):
     (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE; not doubled for
     the kernels whose reads are narrow gathers -- scripts/profile_rows.py says which and why).  None when
     there is no pass for this row OR the passes were taken on another build of the kernels (the file
-    records the sha256 of the device sources it was measured on)."""
+    records the sha256 of the kernel source files it was measured on and of the device assembly made from them)."""
     global PROFILED_ROWS
     if PROFILED_ROWS is None:
         PROFILED_ROWS = {}
@@ -492,7 +508,9 @@ def profiled(label: str, phase: str):
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_rows.json")), reverse=True):  # (the newest round first)
             with open(path) as f:
                 table = json.load(f)
-            if table.get("kernel_source_sha16") == kernel_source_id():
+            # (the same sources, or -- host code or comments of a kernel file changed since -- the same device assembly)
+            if table.get("kernel_source_sha16") == kernel_source_id() or (
+                    table.get("device_asm_sha16") and table.get("device_asm_sha16") == device_asm_id()):
                 PROFILED_ROWS = table.get("rows", {})
                 break
     return PROFILED_ROWS.get(label, {}).get(phase)

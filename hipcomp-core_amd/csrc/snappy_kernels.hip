@@ -34,6 +34,8 @@
 #include "placement.hiph"
 #include "wave_utils.hpp"
 
+#include <atomic>
+
 namespace hcamd {
 
 namespace {
@@ -997,7 +999,8 @@ void snappy_launch_compress(
 namespace {
 unsigned placed_grid(size_t batch)
 {
-  static unsigned resident = 0; // (one device per process in this library's use; the same on every MI355X)
+  static std::atomic<unsigned> known{0}; // (the same on every device of the process)
+  unsigned resident = known.load(std::memory_order_relaxed);
   if (resident == 0) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, snappy_compress_placed_kernel, kWave, 0) != hipSuccess
@@ -1006,6 +1009,7 @@ unsigned placed_grid(size_t batch)
       return 0;
     }
     resident = (unsigned)per_cu * (unsigned)num_cus_of_current_device();
+    known.store(resident, std::memory_order_relaxed);
   }
   return batch < resident ? (unsigned)batch : resident;
 }

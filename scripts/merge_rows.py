@@ -7,7 +7,8 @@ for p in sys.argv[2:]:
     if out is None:
         out = t
     else:
-        assert t["kernel_source_sha16"] == out["kernel_source_sha16"], "parts from different kernel builds"
+        assert t["kernel_source_sha16"] == out["kernel_source_sha16"] or (
+            t.get("device_asm_sha16") and t.get("device_asm_sha16") == out.get("device_asm_sha16")), "parts from different kernel builds"
         out["rows"].update(t["rows"])
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(sys.argv[1], sorted(out["rows"]))

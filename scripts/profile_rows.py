@@ -54,7 +54,7 @@ def working(values):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     import bench
-    table = {"_how": __doc__.split("\n\n", 1)[1].strip(), "kernel_source_sha16": bench.kernel_source_id(), "rows": {}}
+    table = {"_how": __doc__.split("\n\n", 1)[1].strip(), "kernel_source_sha16": bench.kernel_source_id(), "device_asm_sha16": bench.device_asm_id(), "rows": {}}
     for spec in sys.argv[3:]:
         row, k = spec.split("=")
         dur = trace_durations(os.path.join(src, "stats_" + k))

@@ -198,3 +198,24 @@ def test_product_library_reads_nothing_from_the_environment_and_knobs_build_is_t
         k = os.path.join(CSRC, "build_knobs", os.path.basename(f))
         assert os.path.exists(k), k
         assert device_code(f) == device_code(k), os.path.basename(f)
+
+
+def test_committed_profiles_belong_to_the_build_at_hand():
+    """bench.py attaches the committed rocprof numbers (profiles/rNN_rows.json) to its rows only when they were
+    taken on THIS build of the kernels: the same kernel source files, or -- host code or comments of such a file
+    changed since -- the same device assembly (csrc/build/*.gfx950.s, which build() leaves there)."""
+    import glob
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_rows.json")), reverse=True)
+    assert tables, "no profiles/rNN_rows.json"
+    newest = json.load(open(tables[0]))
+    asm = bench.device_asm_id()
+    assert asm is not None, "csrc/build/*.gfx950.s missing: run __graft_entry__.build()"
+    assert newest.get("kernel_source_sha16") == bench.kernel_source_id() or newest.get("device_asm_sha16") == asm, (
+        f"{tables[0]} was measured on other kernels (sources {newest.get('kernel_source_sha16')}, assembly "
+        f"{newest.get('device_asm_sha16')}; here {bench.kernel_source_id()}, {asm}): collect the rows again "
+        "(scripts/collect_profiles.sh) or bench.py reports roofline.traffic = null")
+    bench.PROFILED_ROWS = None
+    assert bench.profiled("lz4/uniform/char/100000", "compress") is not None
